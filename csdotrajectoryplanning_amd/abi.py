@@ -1,0 +1,80 @@
+"""ctypes mirror of include/csdo_dsqp.h (struct layouts only; no library is loaded here).
+
+Field order and types follow the header one for one; the header cites the reference interface each struct replaces.
+"""
+import ctypes as C
+
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+CSDO_OK = 0
+CSDO_EINVAL = -1
+CSDO_ENODEV = -2
+CSDO_ENOMEM = -3
+CSDO_ELIMIT = -4
+CSDO_EDEVICE = -5
+CSDO_MAX_NT = 512
+
+
+class Vehicle(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("r", "deltat", "LF", "LB", "car_width", "WB", "f2x", "r2x", "rv", "obs_radius")]
+
+
+class QpParm(C.Structure):
+    _fields_ = [("r_trust", C.c_double), ("max_omega", C.c_double), ("max_v", C.c_double),
+                ("max_iter", C.c_double), ("delta_solution_threshold", C.c_double),
+                ("max_violation", C.c_double), ("osqp_max_iter", C.c_int32),
+                ("num_interpolation", C.c_int32), ("dt", C.c_double), ("fixed_corridor", C.c_int32),
+                ("adaptive_rho_interval", C.c_int32)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("t", C.c_int32), ("_pad", C.c_int32), ("c", C.c_double * 12)]
+
+
+PLANE_DTYPE = np.dtype([("t", np.int32), ("_pad", np.int32), ("c", np.float64, (12,))])
+assert PLANE_DTYPE.itemsize == C.sizeof(Plane) == 104
+
+
+class Problem(C.Structure):
+    _fields_ = [("Na", C.c_int32), ("Nt", C.c_int32), ("x0_bar", c_double_p), ("plane_off", c_int32_p),
+                ("planes", C.POINTER(Plane)), ("dimx", C.c_double), ("dimy", C.c_double),
+                ("n_obs", C.c_int32), ("_pad", C.c_int32), ("obstacles", c_double_p), ("veh", Vehicle),
+                ("parm", QpParm), ("logger_level", C.c_int32), ("_pad2", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("solutions", c_double_p), ("corridors", c_double_p), ("sqp_iters", c_int32_p),
+                ("admm_iters", c_int32_p), ("last_status", c_int32_p), ("solver_status", C.c_int32),
+                ("initial_static_legal", C.c_int32), ("t_total", C.c_double), ("t_device", C.c_double),
+                ("t_max_individual", C.c_double)]
+
+
+class BridgeOut(C.Structure):
+    _fields_ = [("Na", C.c_int32), ("Nt", C.c_int32), ("x0_bar", c_double_p), ("plane_off", c_int32_p),
+                ("planes", C.POINTER(Plane)), ("n_pairs", C.c_int32), ("initial_inter_legal", C.c_int32),
+                ("pairs", c_int32_p)]
+
+
+def as_double_p(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_int32_p(a):
+    return a.ctypes.data_as(c_int32_p)
+
+
+def as_plane_p(a):
+    return a.ctypes.data_as(C.POINTER(Plane))
+
+
+# Every symbol include/csdo_dsqp.h declares (checked by tests/test_abi.py against the built library).
+EXPORTED_SYMBOLS = (
+    "csdo_dsqp_create", "csdo_dsqp_destroy", "csdo_dsqp_solve", "csdo_dsqp_solve_batch", "csdo_dsqp_upload",
+    "csdo_dsqp_run", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_device_solutions",
+    "csdo_preprocess", "csdo_bridge_free", "csdo_generate_boxes", "csdo_vehicle_default",
+    "csdo_qp_parm_default", "csdo_backend_name",
+)

@@ -1,0 +1,159 @@
+/*
+ * csdo_dsqp.h — C ABI of the MI355X decentralized-optimization (DO) backend for CSDO.
+ *
+ * Drop-in boundary for the reference's `sqp/` subsystem.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree):
+ *
+ *   csdo_dsqp_solve        <->  SolverDSQP::SolverDSQP(...)            sqp/dsqp_solver.h:26-34, .cc:1133-1249
+ *                               + getters getSolverStatus / getMaxOfRuntimes / get_initial_static_legal and the
+ *                               public members num_iterations / corridors   sqp/dsqp_solver.h:41-47
+ *   csdo_dsqp_solve_batch  <->  (extension) several independent worlds in one launch; each world is exactly one
+ *                               SolverDSQP construction
+ *   csdo_preprocess        <->  InterpolateInitalGuess + findNeighborPairsByTrustRegion + calcEqualInterPlanes
+ *                               sqp/inter_agent_cons.h:11-13,40-45,69-73; call sites csdo.cc:116-129
+ *   csdo_generate_boxes    <->  generateBox                            sqp/corridor.h:84-88, .cc:124-159
+ *   csdo_vehicle_default / csdo_qp_parm_default
+ *                          <->  readAgentConfig / readQpSolverConfig   common/motion_planning.cc:54-93,
+ *                               sqp/utils.cc:34-59 evaluated on the shipped config.yaml
+ *
+ * Plain C: pointers + sizes, no C++ or torch types.  All floating point is IEEE binary64 unless noted.
+ * Thread-safety: one call at a time per handle; different handles are independent.  No global mutable state.
+ * Errors: functions return 0 on success or a negative CSDO_E* code; they never abort or throw.
+ */
+#ifndef CSDO_DSQP_H
+#define CSDO_DSQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSDO_OK 0
+#define CSDO_EINVAL (-1)   /* bad argument (null pointer, Nt < 2, sizes inconsistent) */
+#define CSDO_ENODEV (-2)   /* no HIP device / device error */
+#define CSDO_ENOMEM (-3)   /* device or host allocation failed */
+#define CSDO_ELIMIT (-4)   /* problem exceeds a compiled limit (Nt > CSDO_MAX_NT) */
+#define CSDO_EDEVICE (-5)  /* kernel launch / execution failed */
+
+#define CSDO_MAX_NT 512    /* longest supported horizon (one lane per timestep, <= 512 lanes per agent) */
+
+/* OSQP-compatible per-agent status codes reported in last_status[] (osqp/constants.h of OSQP 0.6.3). */
+#define CSDO_STATUS_SOLVED 1
+#define CSDO_STATUS_SOLVED_INACCURATE 2
+#define CSDO_STATUS_PRIMAL_INFEASIBLE_INACCURATE 3
+#define CSDO_STATUS_MAX_ITER_REACHED (-2)
+#define CSDO_STATUS_PRIMAL_INFEASIBLE (-3)
+#define CSDO_STATUS_NON_CVX (-7)
+
+/* Vehicle constants: the reference keeps these as `float` statics (Constants::*, common/motion_planning.h:12-49).
+ * Fields hold the float-rounded values widened to double (e.g. deltat = (double)0.706f). */
+typedef struct csdo_vehicle {
+  double r, deltat;
+  double LF, LB, car_width, WB;
+  double f2x, r2x, rv;   /* derived: motion_planning.cc:82-85 */
+  double obs_radius;
+} csdo_vehicle;
+
+/* QpParm mirror (sqp/common.h:39-52) + the one restatement parameter. */
+typedef struct csdo_qp_parm {
+  double r_trust, max_omega, max_v, max_iter, delta_solution_threshold, max_violation;
+  int32_t osqp_max_iter;
+  int32_t num_interpolation;
+  double dt;
+  int32_t fixed_corridor;
+  /* OSQP's default adaptive_rho_interval = 0 chooses the rho-update period from wall-clock timing; this backend
+   * pins it (0 here means the documented default, 25). */
+  int32_t adaptive_rho_interval;
+} csdo_qp_parm;
+
+/* InterPlane (sqp/inter_agent_cons.h:47-63): c = {a_f2f,b_f2f,c_f2f, a_f2r,b_f2r,c_f2r, a_r2f,.., a_r2r,b_r2r,c_r2r} */
+typedef struct csdo_plane {
+  int32_t t;
+  int32_t _pad;
+  double c[12];
+} csdo_plane;
+
+/* One world = one SolverDSQP construction. */
+typedef struct csdo_problem {
+  int32_t Na, Nt;
+  const double* x0_bar;        /* [Na][Nt][6]: x, y, yaw, steer, v, d_steer (OptimizeResult minus `a`) */
+  const int32_t* plane_off;    /* [Na+1] CSR offsets into planes */
+  const csdo_plane* planes;    /* per agent, in pair order (t ascending) */
+  double dimx, dimy;
+  int32_t n_obs;
+  int32_t _pad;
+  const double* obstacles;     /* [n_obs][3]: x, y, r in input order */
+  csdo_vehicle veh;
+  csdo_qp_parm parm;
+  int32_t logger_level;        /* accepted for signature parity; the device path prints nothing */
+  int32_t _pad2;
+} csdo_problem;
+
+typedef struct csdo_result {
+  double* solutions;           /* [Na][Nt][6]  x,y,yaw,steer,v,d_steer; v,d_steer at t=Nt-1 are 0 */
+  double* corridors;           /* [Na][Nt][8]  xf_min,xf_max,yf_min,yf_max,xr_min,xr_max,yr_min,yr_max */
+  int32_t* sqp_iters;          /* [Na]  SolverDSQP::num_iterations */
+  int32_t* admm_iters;         /* [Na]  sum of ADMM iterations over the agent's QPs (new: needed for the metric) */
+  int32_t* last_status;        /* [Na]  status of the agent's last QP */
+  int32_t solver_status;       /* getSolverStatus(): 1 or the "worst" status by dsqp_solver.cc:1224-1237 */
+  int32_t initial_static_legal;/* get_initial_static_legal() */
+  double t_total;              /* seconds, host wall clock of the call (H2D + kernels + D2H) */
+  double t_device;             /* seconds, device time of the solve kernels (HIP events) */
+  double t_max_individual;     /* getMaxOfRuntimes(): slowest agent's device time */
+} csdo_result;
+
+typedef struct csdo_handle_s* csdo_handle;
+
+/* Create / destroy a solver bound to one HIP device.  Device buffers persist across calls and grow on demand. */
+int csdo_dsqp_create(csdo_handle* out, int device_ordinal);
+void csdo_dsqp_destroy(csdo_handle h);
+
+/* Host-buffer entry: upload, solve on the handle's stream, download.  Replaces the SolverDSQP constructor. */
+int csdo_dsqp_solve(csdo_handle h, const csdo_problem* in, csdo_result* out);
+
+/* Several worlds in one launch (agents of all worlds become workgroups of one grid).  results[w] per world. */
+int csdo_dsqp_solve_batch(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds, csdo_result* results);
+
+/* Split-phase form used by bench.py so the timed region starts with inputs resident in HBM:
+ *   upload (H2D, builds the device problem) -> run (kernels only, repeatable) -> download (D2H). */
+int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds);
+int csdo_dsqp_run(csdo_handle h, void* hip_stream /* hipStream_t or NULL for the handle's stream */);
+int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
+/* Device time of the last csdo_dsqp_run in seconds (HIP events on the launch stream) and the kernel's own name. */
+double csdo_dsqp_last_kernel_seconds(csdo_handle h);
+/* Device pointer to the packed solutions of the last run ([sum Na][Nt_stride][6] doubles) for collectives. */
+void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles);
+
+/* Bridge: coarse front-end paths -> fixed-length initial guess + separating planes.
+ *   states: concatenated [sum L_a][3] (x,y,yaw); actions: concatenated [sum (L_a-1)]; path_off[Na+1] in states.
+ *   goals [Na][3].  Outputs are malloc'ed by the library and released with csdo_free. */
+typedef struct csdo_bridge_out {
+  int32_t Na, Nt;
+  double* x0_bar;              /* [Na][Nt][6] */
+  int32_t* plane_off;          /* [Na+1] */
+  csdo_plane* planes;
+  int32_t n_pairs;
+  int32_t initial_inter_legal; /* findNeighborPairsByTrustRegion's return value */
+  int32_t* pairs;              /* [n_pairs][3] = t, i, j */
+} csdo_bridge_out;
+int csdo_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                    const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
+void csdo_bridge_free(csdo_bridge_out* out);
+
+/* Safe boxes for arbitrary points on the device (one lane per point). boxes: [n][4] x_min,y_min,x_max,y_max;
+ * status: [n] bit0 = success, bits 1-2 = initial status (0 legal, 1 out of map, 2 collision). */
+int csdo_generate_boxes(csdo_handle h, const double* points_xy, int32_t n, const double* obstacles, int32_t n_obs,
+                        double dimx, double dimy, const csdo_vehicle* veh, double* boxes, int32_t* status);
+
+/* The shipped config.yaml evaluated the way readAgentConfig / readQpSolverConfig do. */
+void csdo_vehicle_default(csdo_vehicle* v);
+void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p);
+
+/* Library identification: returns "hip-gfx950". */
+const char* csdo_backend_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSDO_DSQP_H */

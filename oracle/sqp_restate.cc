@@ -1,0 +1,805 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sqp_restate.h).
+#include "sqp_restate.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <thread>
+
+namespace csdo_oracle {
+
+using clk = std::chrono::steady_clock;
+static double secs_since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+// =========================================================================================================
+// common/motion_planning.{h,cc}
+// =========================================================================================================
+void Vehicle::derive() {  // motion_planning.cc:82-85 (double expression assigned to float statics)
+  f2x = (float)(1 / 4.0 * (3.0 * LF - LB));
+  r2x = (float)(1 / 4.0 * (LF - 3.0 * LB));
+  rv = (float)(1.0 / 2.0 * std::pow(std::pow(LF + LB, 2) / 4 + carWidth * carWidth, 0.5));
+}
+
+double qp_dt(const Vehicle& v, double max_v, int num_interpolation, double decelerate_factor) {
+  // utils.cc:55-56: float*float product, then double divisions
+  return v.r * v.deltat / max_v / (num_interpolation + 1) / decelerate_factor;
+}
+
+float normalize_angle_abs_in_pi(double x) {  // motion_planning.h:70-75 (returns float)
+  x = std::fmod(x + M_PI, 2 * M_PI);
+  if (x < 0) x += 2 * M_PI;
+  return (float)(x - M_PI);
+}
+
+DiscCentres state_discs(double x, double y, double yaw, const Vehicle& v) {  // State ctor, :115-132
+  DiscCentres d;
+  d.xf = (float)(x + v.f2x * std::cos(yaw));
+  d.xr = (float)(x + v.r2x * std::cos(yaw));
+  d.yf = (float)(y + v.f2x * std::sin(yaw));
+  d.yr = (float)(y + v.r2x * std::sin(yaw));
+  const float d_center2real = (v.LF + v.LB) / 2 - v.LB;
+  d.xc = (float)(x + d_center2real * std::cos(yaw));
+  d.yc = (float)(y + d_center2real * std::sin(yaw));
+  return d;
+}
+
+static inline double sq_of_float_diff(float a, float b) {
+  // pow(float - float, 2): the difference is formed in float, pow promotes to double
+  const float df = a - b;
+  return std::pow((double)df, 2);
+}
+double agent_distance(const DiscCentres& a, const DiscCentres& b) {  // :208-217
+  double d = sq_of_float_diff(a.xf, b.xf) + sq_of_float_diff(a.yf, b.yf);
+  d = std::min(d, sq_of_float_diff(a.xf, b.xr) + sq_of_float_diff(a.yf, b.yr));
+  d = std::min(d, sq_of_float_diff(a.xr, b.xf) + sq_of_float_diff(a.yr, b.yf));
+  d = std::min(d, sq_of_float_diff(a.xr, b.xr) + sq_of_float_diff(a.yr, b.yr));
+  return std::sqrt(d);
+}
+
+bool agent_collision(const DiscCentres& a, double yaw_a, const DiscCentres& b, double yaw_b,
+                     const Vehicle& v) {  // :140-183, PRCISE_COLLISION branch, all-float arithmetic
+  const float length = v.LF + v.LB;
+  const float width = v.carWidth;
+  const float shift_x = b.xc - a.xc;
+  const float shift_y = b.yc - a.yc;
+  const float cos_v = (float)std::cos(yaw_a), sin_v = (float)std::sin(yaw_a);
+  const float cos_o = (float)std::cos(yaw_b), sin_o = (float)std::sin(yaw_b);
+  const float half_l_v = length / 2, half_w_v = width / 2, half_l_o = length / 2, half_w_o = width / 2;
+  const float dx1 = cos_v * length / 2, dy1 = sin_v * length / 2;
+  const float dx2 = sin_v * width / 2, dy2 = -cos_v * width / 2;
+  const float dx3 = cos_o * length / 2, dy3 = sin_o * length / 2;
+  const float dx4 = sin_o * width / 2, dy4 = -cos_o * width / 2;
+  return (std::fabs(shift_x * cos_v + shift_y * sin_v) <=
+              std::fabs(dx3 * cos_v + dy3 * sin_v) + std::fabs(dx4 * cos_v + dy4 * sin_v) + half_l_v) &&
+         (std::fabs(shift_x * sin_v - shift_y * cos_v) <=
+              std::fabs(dx3 * sin_v - dy3 * cos_v) + std::fabs(dx4 * sin_v - dy4 * cos_v) + half_w_v) &&
+         (std::fabs(shift_x * cos_o + shift_y * sin_o) <=
+              std::fabs(dx1 * cos_o + dy1 * sin_o) + std::fabs(dx2 * cos_o + dy2 * sin_o) + half_l_o) &&
+         (std::fabs(shift_x * sin_o - shift_y * cos_o) <=
+              std::fabs(dx1 * sin_o - dy1 * cos_o) + std::fabs(dx2 * sin_o - dy2 * cos_o) + half_w_o);
+}
+
+// =========================================================================================================
+// sqp/inter_agent_cons.cc — bridge
+// =========================================================================================================
+namespace {
+struct Pose {
+  double x, y, yaw;
+};
+
+// calcActionD, :169-190
+void action_increment(int action, double da, double r, double& dx, double& dy, double& dyaw) {
+  const double fwd = r * da, arc = r * std::sin(da), lat = r * (1 - std::cos(da));
+  switch (action) {
+    case 0: dx = fwd;  dy = 0;    dyaw = 0;   break;
+    case 1: dx = arc;  dy = -lat; dyaw = -da; break;
+    case 2: dx = arc;  dy = lat;  dyaw = da;  break;
+    case 3: dx = -fwd; dy = 0;    dyaw = 0;   break;
+    case 4: dx = -arc; dy = -lat; dyaw = da;  break;
+    case 5: dx = -arc; dy = lat;  dyaw = -da; break;
+    default: assert(false && "unknown action"); dx = dy = dyaw = 0;
+  }
+}
+
+// action_sample, :194-271.  Appends n intermediate poses and the head of the next segment.
+void sample_segment(int action, const Pose& s0, const Pose& s1, int n, const Vehicle& veh,
+                    std::vector<Pose>& out_states, std::vector<int>& out_actions) {
+  for (int i = 0; i < n + 1; ++i) out_actions.push_back(action);
+  if (action == 6) {  // wait: copies of s0
+    for (int i = 1; i < n + 2; ++i) out_states.push_back(s0);
+    return;
+  }
+  double r = veh.r;
+  double deltat;
+  if (action == 0 || action == 3) {
+    deltat = std::sqrt(std::pow(s1.x - s0.x, 2) + std::pow(s1.y - s0.y, 2)) / veh.r;
+  } else {
+    deltat = normalize_angle_abs_in_pi(s1.yaw - s0.yaw);
+    const double d = std::sqrt(std::pow(s1.x - s0.x, 2) + std::pow(s1.y - s0.y, 2));
+    r = d / (2.0 * std::sin(std::fabs(deltat) / 2.0));  // re-fitted arc radius
+  }
+  const double deltat_abs = std::fabs(deltat);
+  double dx, dy, dyaw;
+  action_increment(action, deltat_abs / (double)(n + 1), r, dx, dy, dyaw);
+  Pose s = s0;
+  for (int i = 1; i < n + 1; ++i) {
+    Pose nx;
+    nx.x = s.x + dx * std::cos(s.yaw) - dy * std::sin(s.yaw);
+    nx.y = s.y + dx * std::sin(s.yaw) + dy * std::cos(s.yaw);
+    nx.yaw = s.yaw + dyaw;
+    out_states.push_back(nx);
+    s = nx;
+  }
+  const double dyaw_total = (action == 0 || action == 3) ? 0.0 : deltat;
+  out_states.push_back(Pose{s1.x, s1.y, dyaw_total + s0.yaw});
+}
+}  // namespace
+
+void interpolate_initial_guess(std::vector<CoarsePath> paths, const std::vector<std::array<double, 3>>& goals,
+                               const QpParm& parm, const Vehicle& veh,
+                               std::vector<std::vector<OptRes>>& x0_bar) {
+  const size_t Na = paths.size();
+  for (size_t a = 0; a < goals.size(); ++a) paths[a].states.back() = goals[a];  // :149-151
+
+  // interpolateXYYaw, :277-310
+  std::vector<std::vector<Pose>> fine(Na);
+  std::vector<std::vector<int>> fine_actions(Na);
+  const int n = parm.num_interpolation;
+  for (size_t a = 0; a < Na; ++a) {
+    const auto& P = paths[a];
+    assert(P.states.size() == P.actions.size() + 1);
+    Pose s{P.states[0][0], P.states[0][1], P.states[0][2]};
+    fine[a].push_back(s);
+    for (size_t i = 0; i + 1 < P.states.size(); ++i) {
+      const Pose s1{P.states[i + 1][0], P.states[i + 1][1], P.states[i + 1][2]};
+      sample_segment(P.actions[i], s, s1, n, veh, fine[a], fine_actions[a]);
+      s = fine[a].back();
+    }
+  }
+
+  // calcVSteerW, :315-411
+  size_t Nt = 0;
+  for (size_t a = 0; a < Na; ++a) Nt = std::max(Nt, fine[a].size());
+  x0_bar.assign(Na, std::vector<OptRes>(Nt));
+  const double dt = parm.dt;
+  const double phi_action = (double)std::atan((veh.LF - veh.LB) / veh.r);  // float atan, :352-353
+  for (size_t a = 0; a < Na; ++a) {
+    auto& g = x0_bar[a];
+    const size_t xs = fine[a].size();
+    for (size_t i = 0; i < xs; ++i) {
+      g[i].x = fine[a][i].x;
+      g[i].y = fine[a][i].y;
+      g[i].yaw = fine[a][i].yaw;
+    }
+    for (size_t i = xs; i < Nt; ++i) {
+      g[i].x = fine[a].back().x;
+      g[i].y = fine[a].back().y;
+      g[i].yaw = fine[a].back().yaw;
+    }
+    g[0].steer = 0;
+    for (size_t i = 1; i < xs; ++i) {
+      const int act = fine_actions[a][i - 1];
+      double phi = 0;
+      if (act == 1 || act == 4) phi = -phi_action;
+      else if (act == 2 || act == 5) phi = phi_action;
+      g[i].steer = phi;
+    }
+    for (size_t i = xs; i < Nt; ++i) g[i].steer = 0;
+    for (size_t i = 0; i + 1 < xs; ++i) {
+      g[i].v = ((g[i + 1].x - g[i].x) / dt) * std::cos(g[i].yaw) + ((g[i + 1].y - g[i].y) / dt) * std::sin(g[i].yaw);
+      g[i].d_steer = (g[i + 1].steer - g[i].steer) / dt;
+    }
+    // entries xs-1 .. Nt-1 keep v = d_steer = 0 (value-initialised, and :400-403)
+  }
+}
+
+bool find_neighbor_pairs(const std::vector<std::vector<OptRes>>& sol, double r_trust, const Vehicle& veh,
+                         std::vector<std::array<int, 3>>& pairs) {  // :12-49
+  bool ok = true;
+  const int Na = (int)sol.size();
+  const int Nt = (int)sol[0].size();
+  const double thresh = 2 * std::sqrt(2) * r_trust;
+  for (int t = 0; t < Nt; ++t) {
+    for (int i = 0; i < Na - 1; ++i) {
+      const DiscCentres si = state_discs(sol[i][t].x, sol[i][t].y, sol[i][t].yaw, veh);
+      for (int j = i + 1; j < Na; ++j) {
+        const DiscCentres sj = state_discs(sol[j][t].x, sol[j][t].y, sol[j][t].yaw, veh);
+        const double d = agent_distance(si, sj);
+        if (d < thresh) {
+          pairs.push_back({t, i, j});
+          if (agent_collision(si, sol[i][t].yaw, sj, sol[j][t].yaw, veh)) ok = false;
+        }
+      }
+    }
+  }
+  return ok;
+}
+
+namespace {
+// calcPerpendicular, :54-69: bisector a x + b y + c <= 0 between p1 and p2, shifted by rv*|p2-p1| either way
+void perpendicular(double x1, double y1, double x2, double y2, const Vehicle& veh, double& a, double& b,
+                   double& c1, double& c2) {
+  const double rv = veh.rv;
+  a = x2 - x1;
+  b = y2 - y1;
+  const double c = (x1 * x1 + y1 * y1 - x2 * x2 - y2 * y2) / 2;
+  const double d = std::sqrt(std::pow(x1 - x2, 2) + std::pow(y1 - y2, 2));
+  c1 = c + rv * d;
+  c2 = c - rv * d;
+}
+}  // namespace
+
+void calc_inter_planes(const std::vector<std::vector<OptRes>>& x0_bar,
+                       const std::vector<std::array<int, 3>>& pairs, const Vehicle& veh,
+                       std::vector<std::vector<InterPlane>>& planes) {  // :71-140
+  planes.assign(x0_bar.size(), {});
+  for (const auto& p : pairs) {
+    const int t = p[0], ai = p[1], aj = p[2];
+    const OptRes& ri = x0_bar[ai][t];
+    const OptRes& rj = x0_bar[aj][t];
+    const DiscCentres di = state_discs(ri.x, ri.y, ri.yaw, veh);
+    const DiscCentres dj = state_discs(rj.x, rj.y, rj.yaw, veh);
+    const double xfi = di.xf, yfi = di.yf, xri = di.xr, yri = di.yr;
+    const double xfj = dj.xf, yfj = dj.yf, xrj = dj.xr, yrj = dj.yr;
+    double a_f2f, b_f2f, c_f2f, c_f2f_, a_f2r, b_f2r, c_f2r, c_f2r_;
+    double a_r2f, b_r2f, c_r2f, c_r2f_, a_r2r, b_r2r, c_r2r, c_r2r_;
+    perpendicular(xfi, yfi, xfj, yfj, veh, a_f2f, b_f2f, c_f2f, c_f2f_);
+    perpendicular(xfi, yfi, xrj, yrj, veh, a_f2r, b_f2r, c_f2r, c_f2r_);
+    perpendicular(xri, yri, xfj, yfj, veh, a_r2f, b_r2f, c_r2f, c_r2f_);
+    perpendicular(xri, yri, xrj, yrj, veh, a_r2r, b_r2r, c_r2r, c_r2r_);
+    InterPlane pi, pj;
+    pi.t = pj.t = t;
+    const double ci[12] = {a_f2f, b_f2f, c_f2f, a_f2r, b_f2r, c_f2r, a_r2f, b_r2f, c_r2f, a_r2r, b_r2r, c_r2r};
+    // agent j sees the negated planes with the f2r / r2f roles swapped (:131-135)
+    const double cj[12] = {-a_f2f, -b_f2f, -c_f2f_, -a_r2f, -b_r2f, -c_r2f_,
+                           -a_f2r, -b_f2r, -c_f2r_, -a_r2r, -b_r2r, -c_r2r_};
+    std::copy(ci, ci + 12, pi.c);
+    std::copy(cj, cj + 12, pj.c);
+    planes[ai].push_back(pi);
+    planes[aj].push_back(pj);
+  }
+}
+
+// =========================================================================================================
+// sqp/corridor.cc
+// =========================================================================================================
+namespace {
+inline Box expand(Box b, int dir, double ds) {  // corridor.h:26-48
+  if (dir == 0) b.y_max += ds;
+  else if (dir == 1) b.x_min -= ds;
+  else if (dir == 2) b.y_min -= ds;
+  else b.x_max += ds;
+  return b;
+}
+inline bool obstacle_inside_inflated(const Box& box, const Obstacle& o, double rv) {
+  Box d = box;
+  for (int i = 0; i < 4; ++i) d = expand(d, i, o.r + rv);
+  return d.x_min < o.x && o.x < d.x_max && d.y_min < o.y && o.y < d.y_max;
+}
+bool point_out_of_map(double x, double y, double dimx, double dimy, const Vehicle& v) {  // :25-30
+  const double rv = v.rv;
+  return x < rv || x > dimx - rv || y < rv || y > dimy - rv;
+}
+// isPointCollision, :32-52.  DELIBERATE DEVIATION: the reference returns the first hit in
+// unordered_set iteration order (libstdc++ bucket order of boost::hash_combine); we return the lowest input index.
+int point_collision(double x, double y, const std::vector<Obstacle>& obs, const Vehicle& v) {
+  const double rv = v.rv;
+  const Box b{x, y, x, y};
+  for (size_t k = 0; k < obs.size(); ++k)
+    if (obstacle_inside_inflated(b, obs[k], rv)) return (int)k;
+  return -1;
+}
+void project_near_border(double dimx, double dimy, double& x, double& y, const Vehicle& v) {  // :54-81
+  const double rv = v.rv, eps = 1e-3;
+  const double x0 = x, y0 = y;
+  if (x0 < rv) x = rv + eps;
+  else if (x0 > dimx - rv) x = dimx - rv - eps;
+  if (y0 < rv) y = rv + eps;
+  else if (y0 > dimy - rv) y = dimy - rv - eps;
+}
+}  // namespace
+
+bool is_box_valid(const Box& b, const std::vector<Obstacle>& obs, double dimx, double dimy, const Vehicle& v) {
+  const double rv = v.rv;  // :252-272
+  if (b.x_min < rv || b.x_max > dimx - rv || b.y_min < rv || b.y_max > dimy - rv) return false;
+  for (const auto& o : obs)
+    if (obstacle_inside_inflated(b, o, rv)) return false;
+  return true;
+}
+
+bool generate_local_box(double xc, double yc, const std::vector<Obstacle>& obs, double dimx, double dimy,
+                        const Vehicle& v, Box& res, double ds, double l_limit) {  // :278-324
+  int id[4] = {0, 1, 2, 3};  // +y, -x, -y, +x round robin
+  double lens[4] = {0, 0, 0, 0};
+  Box box{xc, yc, xc, yc};
+  int num_expand = 0, n_valid = 4;
+  while (n_valid > 0) {
+    for (int k = 0; k < 4; ++k) {
+      const int i = id[k];
+      if (i == -1) continue;
+      const Box trial = expand(box, i, ds);
+      if (is_box_valid(trial, obs, dimx, dimy, v)) {
+        num_expand++;
+        lens[i] += ds;
+        box = trial;
+        if (lens[i] >= l_limit) {
+          n_valid--;
+          id[i] = -1;
+        }
+      } else {
+        n_valid--;
+        id[i] = -1;
+      }
+    }
+  }
+  res = box;
+  return num_expand > 0;
+}
+
+namespace {
+// generateLegalPoint, :84-122
+bool generate_legal_point(const Obstacle& hit, const std::vector<Obstacle>& obs, double dimx, double dimy,
+                          double& x, double& y, const Vehicle& v, Box& res) {
+  const int n_cand = 20;
+  const double x0 = x, y0 = y;
+  const double theta0 = std::atan2(y0 - hit.y, x0 - hit.x);
+  const double d_safe = 0.2;
+  const double d = v.rv + hit.r + d_safe;
+  for (int i = 0; i < n_cand; ++i) {
+    int j = i / 2;
+    if (i % 2 == 1) j = -j;
+    const double theta = theta0 + j * 2 * M_PI / n_cand;
+    x = hit.x + d * std::cos(theta);
+    y = hit.y + d * std::sin(theta);
+    if (x > v.rv && x < dimx - v.rv && y > v.rv && y < dimy - v.rv) {
+      Box box{0, 0, 0, 0};
+      generate_local_box(x, y, obs, dimx, dimy, v, box);
+      if (is_box_valid(box, obs, dimx, dimy, v)) {
+        res = box;
+        return true;
+      }
+    }
+  }
+  res = Box{x, y, x, y};  // zero-area fallback, :117-121
+  return false;
+}
+}  // namespace
+
+BoxStatus generate_box(double dimx, double dimy, double x, double y, const std::vector<Obstacle>& obs,
+                       const Vehicle& v, Box& res) {  // :124-159
+  BoxStatus st{false, 0};
+  Box box{x, y, x, y};
+  if (point_out_of_map(x, y, dimx, dimy, v)) {
+    st.initial_status = 1;
+    project_near_border(dimx, dimy, x, y, v);
+  }
+  const int hit = point_collision(x, y, obs, v);
+  if (hit >= 0) {
+    st.initial_status = 2;
+    st.success = generate_legal_point(obs[hit], obs, dimx, dimy, x, y, v, box);
+  } else {
+    st.success = generate_local_box(x, y, obs, dimx, dimy, v, box);
+  }
+  res = box;
+  return st;
+}
+
+bool calc_corridors(const std::vector<std::vector<OptRes>>& guesses, const std::vector<Obstacle>& obs,
+                    double dimx, double dimy, const Vehicle& v, std::vector<std::vector<Corridor>>& corridors,
+                    double& time_max_corridor) {  // :164-248
+  bool initial_success = true;
+  const size_t Na = guesses.size(), Nt = guesses[0].size();
+  corridors.assign(Na, std::vector<Corridor>(Nt));
+  time_max_corridor = 0;
+  for (size_t a = 0; a < Na; ++a) {
+    const auto t0 = clk::now();
+    for (size_t i = 0; i < Nt; ++i) {
+      const DiscCentres dc = state_discs(guesses[a][i].x, guesses[a][i].y, guesses[a][i].yaw, v);
+      Box bf{0, 0, 0, 0}, br{0, 0, 0, 0};
+      const BoxStatus sf = generate_box(dimx, dimy, dc.xf, dc.yf, obs, v, bf);
+      const BoxStatus sr = generate_box(dimx, dimy, dc.xr, dc.yr, obs, v, br);
+      if (sf.initial_status > 0 || sr.initial_status > 0) initial_success = false;
+      corridors[a][i] = Corridor{bf.x_min, bf.x_max, bf.y_min, bf.y_max, br.x_min, br.x_max, br.y_min, br.y_max};
+    }
+    time_max_corridor = std::max(time_max_corridor, secs_since(t0));
+  }
+  return initial_success;
+}
+
+// =========================================================================================================
+// sqp/dsqp_solver.cc
+// =========================================================================================================
+void assemble_qp(int Nt, const std::vector<double>& s, const std::vector<double>& corr_lb,
+                 const std::vector<double>& corr_ub, const std::vector<double>& x_trust,
+                 const std::vector<double>& y_trust, const double cfg[6],
+                 const std::vector<InterPlane>& planes, const QpParm& parm, const Vehicle& veh, AgentQp& qp) {
+  const int Nm = Nt - 1;
+  const int n_vars = 4 * Nt + 2 * Nm;
+  const int n_kine = 4 * Nm, n_config = 6, n_2circle = 4 * Nt, n_trust = 2 * Nt, n_ctrls = 2 * Nm;
+  const int n_inter = 4 * (int)planes.size();
+  const int m = n_kine + n_config + n_2circle + n_trust + n_ctrls + Nt + n_inter;
+  const double dt = parm.dt;
+  const double WB = veh.WB;
+  const double steer_max = std::atan(WB / veh.r);  // :1178
+  const double* x0 = &s[0];
+  const double* y0 = &s[Nt];
+  const double* yaw0 = &s[2 * Nt];
+  const double* st0 = &s[3 * Nt];
+  const double* v0 = &s[4 * Nt];
+  const int oX = 0, oY = Nt, oYaw = 2 * Nt, oSt = 3 * Nt, oV = 4 * Nt, oW = 4 * Nt + Nm;
+  (void)x0; (void)y0;
+
+  TripletList T;
+  qp.l.assign(m, 0.0);
+  qp.u.assign(m, 0.0);
+  int si = 0;
+  // ---- calcKineConstraint, :646-744 ----
+  for (int k = 0; k < Nm; ++k) {
+    const double syaw = std::sin(yaw0[k]), cyaw = std::cos(yaw0[k]);
+    const double cst = std::cos(st0[k]);
+    const double a_yaw1 = -dt * (v0[k] * syaw);
+    const double a_yaw2 = dt * (v0[k] * cyaw);
+    const double a_steer = (dt / WB * v0[k]) / std::pow(cst, 2);
+    // x rows
+    T.add(si + k, oX + k, 1);
+    T.add(si + k, oX + k + 1, -1);
+    T.add(si + k, oYaw + k, a_yaw1);
+    T.add(si + k, oV + k, dt * cyaw);
+    // y rows
+    T.add(si + Nm + k, oY + k, 1);
+    T.add(si + Nm + k, oY + k + 1, -1);
+    T.add(si + Nm + k, oYaw + k, a_yaw2);
+    T.add(si + Nm + k, oV + k, dt * syaw);
+    // yaw rows
+    T.add(si + 2 * Nm + k, oYaw + k, 1);
+    T.add(si + 2 * Nm + k, oYaw + k + 1, -1);
+    T.add(si + 2 * Nm + k, oSt + k, a_steer);
+    T.add(si + 2 * Nm + k, oV + k, dt / WB * std::tan(st0[k]));
+    // steer rows
+    T.add(si + 3 * Nm + k, oSt + k, 1);
+    T.add(si + 3 * Nm + k, oSt + k + 1, -1);
+    T.add(si + 3 * Nm + k, oW + k, dt * 1.0);
+    // l = u = -C, :717-718,741-742
+    const double C0 = dt * yaw0[k] * v0[k] * syaw;
+    const double C1 = -dt * yaw0[k] * v0[k] * cyaw;
+    const double C2 = -dt * (st0[k] * v0[k] / WB / std::pow(cst, 2));
+    qp.l[si + k] = qp.u[si + k] = -C0;
+    qp.l[si + Nm + k] = qp.u[si + Nm + k] = -C1;
+    qp.l[si + 2 * Nm + k] = qp.u[si + 2 * Nm + k] = -C2;
+    qp.l[si + 3 * Nm + k] = qp.u[si + 3 * Nm + k] = -0.0;
+  }
+  si += n_kine;
+  // ---- calcCfgConstraint, :746-788 ----
+  {
+    const int cols[6] = {oX, oX + Nt - 1, oY, oY + Nt - 1, oYaw, oYaw + Nt - 1};
+    for (int r = 0; r < 6; ++r) {
+      T.add(si + r, cols[r], 1);
+      qp.l[si + r] = qp.u[si + r] = cfg[r];
+    }
+  }
+  si += n_config;
+  // ---- calcCorridorConstraint, :874-968 ----
+  const double f2x = veh.f2x, r2x = veh.r2x;
+  std::vector<double> E(4 * Nt);
+  std::vector<double> Dyaw(4 * Nt);  // yaw coefficient of rows xf,yf,xr,yr
+  for (int t = 0; t < Nt; ++t) {
+    const double sy = std::sin(yaw0[t]), cy = std::cos(yaw0[t]);
+    Dyaw[t] = -f2x * sy;
+    Dyaw[Nt + t] = f2x * cy;
+    Dyaw[2 * Nt + t] = -r2x * sy;
+    Dyaw[3 * Nt + t] = r2x * cy;
+    E[t] = f2x * (cy + yaw0[t] * sy);
+    E[Nt + t] = f2x * (sy - yaw0[t] * cy);
+    E[2 * Nt + t] = r2x * (cy + yaw0[t] * sy);
+    E[3 * Nt + t] = r2x * (sy - yaw0[t] * cy);
+  }
+  for (int b = 0; b < 4; ++b)
+    for (int t = 0; t < Nt; ++t) {
+      const int row = si + b * Nt + t;
+      T.add(row, ((b % 2 == 0) ? oX : oY) + t, 1);
+      T.add(row, oYaw + t, Dyaw[b * Nt + t]);
+      qp.l[row] = corr_lb[b * Nt + t] - E[b * Nt + t];
+      qp.u[row] = corr_ub[b * Nt + t] - E[b * Nt + t];
+    }
+  si += n_2circle;
+  // ---- calcTrustRegionConstraint, :970-994 ----
+  for (int t = 0; t < Nt; ++t) {
+    T.add(si + t, oX + t, 1);
+    T.add(si + Nt + t, oY + t, 1);
+    qp.l[si + t] = -parm.r_trust + x_trust[t];
+    qp.u[si + t] = parm.r_trust + x_trust[t];
+    qp.l[si + Nt + t] = -parm.r_trust + y_trust[t];
+    qp.u[si + Nt + t] = parm.r_trust + y_trust[t];
+  }
+  si += n_trust;
+  // ---- calcMaxCtrlAndSteerConstraint, :996-1039 ----
+  for (int k = 0; k < Nm; ++k) {
+    T.add(si + k, oV + k, 1);
+    T.add(si + Nm + k, oW + k, 1);
+    qp.l[si + k] = -parm.max_v;
+    qp.u[si + k] = parm.max_v;
+    qp.l[si + Nm + k] = -parm.max_omega;
+    qp.u[si + Nm + k] = parm.max_omega;
+  }
+  for (int t = 0; t < Nt; ++t) {
+    T.add(si + n_ctrls + t, oSt + t, 1);
+    qp.l[si + n_ctrls + t] = -steer_max;
+    qp.u[si + n_ctrls + t] = steer_max;
+  }
+  si += n_ctrls + Nt;
+  // ---- calcInterVehicleConstraint, :1041-1129: rows of G*D, u = -(H + G*E), l = -inf ----
+  const double inf = std::numeric_limits<double>::infinity();
+  for (size_t k = 0; k < planes.size(); ++k) {
+    const InterPlane& pl = planes[k];
+    const int t = pl.t;
+    for (int r = 0; r < 4; ++r) {
+      const double a = pl.c[3 * r], b = pl.c[3 * r + 1], c = pl.c[3 * r + 2];
+      const int ex = (r < 2) ? t : 2 * Nt + t;       // xf or xr row of D/E
+      const int ey = (r < 2) ? Nt + t : 3 * Nt + t;  // yf or yr
+      const int row = si + 4 * (int)k + r;
+      T.add(row, oX + t, a * 1.0);
+      T.add(row, oY + t, b * 1.0);
+      T.add(row, oYaw + t, a * Dyaw[ex] + b * Dyaw[ey]);
+      const double GE = 0.0 + a * E[ex] + b * E[ey];
+      qp.u[row] = -(c + GE);
+      qp.l[row] = -inf;
+    }
+  }
+  si += n_inter;
+  assert(si == m);
+  qp.A = csc_from_triplets(m, n_vars, T);
+
+  // ---- objective, :163-197: first-difference Laplacian on v, identity on w; upper triangle (:449) ----
+  TripletList TP;
+  for (int t = 0; t < Nm; ++t) {
+    const int iv = oV + t;
+    if (t != 0 && t != Nt - 2) {
+      TP.add(iv, iv, 2);
+      TP.add(iv, iv + 1, -1);
+    } else if (t == 0) {
+      TP.add(iv, iv, 1);
+      if (Nm > 1) TP.add(iv, iv + 1, -1);
+    } else {
+      TP.add(iv, iv, 1);
+    }
+    TP.add(oW + t, oW + t, 1);
+  }
+  qp.P_triu = csc_from_triplets(n_vars, n_vars, TP);
+  qp.q.assign(n_vars, 0.0);
+}
+
+namespace {
+struct AgentCtx {
+  int Nt;
+  std::vector<double> corr_lb, corr_ub;  // [4][Nt]
+};
+
+// isFeasible, :292-420 (fully_check = false)
+bool is_feasible(int Nt, const std::vector<double>& s, const AgentCtx& ctx, const std::vector<InterPlane>& planes,
+                 const QpParm& parm, const Vehicle& veh) {
+  const double th_kin = 1e-2, th_cor = 1e-1, th_inter = 1e-1;
+  const double dt = parm.dt, WB = veh.WB;
+  const double* x = &s[0];
+  const double* y = &s[Nt];
+  const double* yaw = &s[2 * Nt];
+  const double* st = &s[3 * Nt];
+  const double* v = &s[4 * Nt];
+  const double* w = &s[4 * Nt + Nt - 1];
+  double e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+  for (int k = 0; k < Nt - 1; ++k) {
+    const double r1 = x[k] + v[k] * std::cos(yaw[k]) * dt - x[k + 1];
+    const double r2 = y[k] + v[k] * std::sin(yaw[k]) * dt - y[k + 1];
+    const double r3 = yaw[k] + v[k] * std::tan(st[k]) / WB * dt - yaw[k + 1];
+    const double r4 = st[k] + w[k] * dt - st[k + 1];
+    e1 += r1 * r1;
+    e2 += r2 * r2;
+    e3 += r3 * r3;
+    e4 += r4 * r4;
+  }
+  const double err_kin = (e1 + e2 + e3 + e4) / Nt;
+  if (err_kin > th_kin) return false;
+  std::vector<double> Y(4 * Nt);
+  for (int t = 0; t < Nt; ++t) {
+    Y[t] = x[t] + veh.f2x * std::cos(yaw[t]);
+    Y[Nt + t] = y[t] + veh.f2x * std::sin(yaw[t]);
+    Y[2 * Nt + t] = x[t] + veh.r2x * std::cos(yaw[t]);
+    Y[3 * Nt + t] = y[t] + veh.r2x * std::sin(yaw[t]);
+  }
+  double err_cor_max = 0;
+  for (int i = 0; i < 4 * Nt; ++i)
+    if (!(ctx.corr_lb[i] <= Y[i])) err_cor_max = std::max(err_cor_max, ctx.corr_lb[i] - Y[i]);
+  if (err_cor_max > th_cor) return false;
+  for (int i = 0; i < 4 * Nt; ++i)
+    if (!(Y[i] <= ctx.corr_ub[i])) err_cor_max = std::max(err_cor_max, Y[i] - ctx.corr_ub[i]);
+  if (err_cor_max > th_cor) return false;
+  double err_inter_max = 0;
+  for (const auto& pl : planes) {  // G*Y + H, :393-405
+    const int t = pl.t;
+    for (int r = 0; r < 4; ++r) {
+      const double px = (r < 2) ? Y[t] : Y[2 * Nt + t];
+      const double py = (r < 2) ? Y[Nt + t] : Y[3 * Nt + t];
+      const double res = (0.0 + px * pl.c[3 * r] + py * pl.c[3 * r + 1]) + pl.c[3 * r + 2];
+      if (res > 0 && res > err_inter_max) err_inter_max = res;
+    }
+  }
+  return err_kin < th_kin && err_inter_max < th_inter && err_cor_max < th_cor;
+}
+
+// updateCorridor, :818-872 (double-precision disc centres)
+void update_corridor(int Nt, const std::vector<double>& s, const DsqpProblem& prob, AgentCtx& ctx,
+                     std::vector<Corridor>& corr) {
+  const Vehicle& veh = prob.veh;
+  for (int t = 0; t < Nt; ++t) {
+    const double x = s[t], y = s[Nt + t], yaw = s[2 * Nt + t];
+    const double xf = x + veh.f2x * std::cos(yaw), xr = x + veh.r2x * std::cos(yaw);
+    const double yf = y + veh.f2x * std::sin(yaw), yr = y + veh.r2x * std::sin(yaw);
+    Box bf{0, 0, 0, 0}, br{0, 0, 0, 0};
+    generate_box(prob.dimx, prob.dimy, xf, yf, prob.obstacles, veh, bf);
+    generate_box(prob.dimx, prob.dimy, xr, yr, prob.obstacles, veh, br);
+    ctx.corr_lb[t] = bf.x_min;
+    ctx.corr_lb[Nt + t] = bf.y_min;
+    ctx.corr_ub[t] = bf.x_max;
+    ctx.corr_ub[Nt + t] = bf.y_max;
+    ctx.corr_lb[2 * Nt + t] = br.x_min;
+    ctx.corr_lb[3 * Nt + t] = br.y_min;
+    ctx.corr_ub[2 * Nt + t] = br.x_max;
+    ctx.corr_ub[3 * Nt + t] = br.y_max;
+    corr[t] = Corridor{bf.x_min, bf.x_max, bf.y_min, bf.y_max, br.x_min, br.x_max, br.y_min, br.y_max};
+  }
+}
+
+// calcIndividualSQP, :36-269
+void individual_sqp(int a, const DsqpProblem& prob, DsqpResult& res, std::vector<SqpTraceEntry>* trace) {
+  const int Nt = (int)prob.x0_bar[a].size();
+  const int Nm = Nt - 1;
+  const int n = 4 * Nt + 2 * Nm;
+  const auto& g = prob.x0_bar[a];
+  // extractResult, utils.cc:93-123
+  std::vector<double> sol0(n);
+  for (int t = 0; t < Nt; ++t) {
+    sol0[t] = g[t].x;
+    sol0[Nt + t] = g[t].y;
+    sol0[2 * Nt + t] = g[t].yaw;
+    sol0[3 * Nt + t] = g[t].steer;
+    if (t < Nm) {
+      sol0[4 * Nt + t] = g[t].v;
+      sol0[4 * Nt + Nm + t] = g[t].d_steer;
+    }
+  }
+  const double cfg[6] = {g.front().x, g.back().x, g.front().y, g.back().y, g.front().yaw, g.back().yaw};
+  const std::vector<double> x_trust(sol0.begin(), sol0.begin() + Nt);       // never moved, :59-60
+  const std::vector<double> y_trust(sol0.begin() + Nt, sol0.begin() + 2 * Nt);
+  AgentCtx ctx;
+  ctx.Nt = Nt;
+  ctx.corr_lb.resize(4 * Nt);
+  ctx.corr_ub.resize(4 * Nt);
+  for (int t = 0; t < Nt; ++t) {  // extractAgentsCorridor, :791-815
+    const Corridor& c = res.corridors[a][t];
+    ctx.corr_lb[t] = c.xf_min;
+    ctx.corr_lb[Nt + t] = c.yf_min;
+    ctx.corr_lb[2 * Nt + t] = c.xr_min;
+    ctx.corr_lb[3 * Nt + t] = c.yr_min;
+    ctx.corr_ub[t] = c.xf_max;
+    ctx.corr_ub[Nt + t] = c.yf_max;
+    ctx.corr_ub[2 * Nt + t] = c.xr_max;
+    ctx.corr_ub[3 * Nt + t] = c.yr_max;
+  }
+  const auto& planes = prob.planes[a];
+  const double th = prob.parm.delta_solution_threshold;
+  double delta = th + 1;
+  const int max_iter = (int)prob.parm.max_iter;
+  int it = 0, status = 1, admm_total = 0;
+  std::vector<double> lin = sol0;  // linearisation point (x0,y0,yaw0,steer0,v0_,w0_)
+  std::vector<double> sol(n);
+
+  // time-major variable order for the LDL^T ordering (rounding-level effect only)
+  std::vector<int> var_order;
+  var_order.reserve(n);
+  for (int t = 0; t < Nt; ++t) {
+    var_order.push_back(t);
+    var_order.push_back(Nt + t);
+    var_order.push_back(2 * Nt + t);
+    var_order.push_back(3 * Nt + t);
+    if (t < Nm) {
+      var_order.push_back(4 * Nt + t);
+      var_order.push_back(4 * Nt + Nm + t);
+    }
+  }
+  Settings st;
+  st.max_iter = prob.parm.osqp_max_iter;
+  st.adaptive_rho_interval = prob.parm.adaptive_rho_interval;
+
+  while (delta > th && it < max_iter) {
+    AgentQp qp;
+    assemble_qp(Nt, lin, ctx.corr_lb, ctx.corr_ub, x_trust, y_trust, cfg, planes, prob.parm, prob.veh, qp);
+    std::vector<double> xs;
+    const Info info = osqp_solve_restated(qp.P_triu, qp.q, qp.A, qp.l, qp.u, sol0, st, xs, nullptr, nullptr,
+                                          &var_order);
+    status = info.status;
+    admm_total += info.iter;
+    if (std::getenv("CSDO_ORACLE_DEBUG"))
+      std::fprintf(stderr, "agent %d sqp %d: status %d iter %d rho_updates %d nnzL %ld n %d m %d nnzA %d\n", a, it,
+                   info.status, info.iter, info.rho_updates, last_factor_nnz(), n, qp.A.m, qp.A.nnz());
+    if (std::abs(status) > 2) sol = sol0;  // :515-524
+    else sol = xs;
+    delta = 0.0;
+    for (int j = 0; j < n; ++j) delta += (sol[j] - sol0[j]) * (sol[j] - sol0[j]);  // :228
+    it++;
+    lin = sol;  // ExtractAndSimplify, :243
+    if (trace) trace->push_back(SqpTraceEntry{a, it, status, info.iter, delta, sol});
+    if (it > max_iter / 2 && is_feasible(Nt, lin, ctx, planes, prob.parm, prob.veh)) break;  // :247
+    sol0 = sol;
+    if (!prob.parm.fixed_corridor) update_corridor(Nt, sol, prob, ctx, res.corridors[a]);
+  }
+  res.sqp_iters[a] = it;
+  res.admm_iters[a] = admm_total;
+  res.last_status[a] = status;
+  auto& out = res.solutions[a];
+  out.assign(Nt, OptRes{});
+  for (int t = 0; t < Nt; ++t) {  // extractSingleSolutionVec2OptRes, :577-617 (v,d_steer of t=Nt-1 defined as 0)
+    out[t].x = sol[t];
+    out[t].y = sol[Nt + t];
+    out[t].yaw = sol[2 * Nt + t];
+    out[t].steer = sol[3 * Nt + t];
+    if (t < Nm) {
+      out[t].v = sol[4 * Nt + t];
+      out[t].d_steer = sol[4 * Nt + Nm + t];
+    }
+  }
+}
+}  // namespace
+
+void dsqp_solve(const DsqpProblem& prob, DsqpResult& res, int n_threads, std::vector<SqpTraceEntry>* trace) {
+  const auto t_begin = clk::now();
+  const int Na = (int)prob.x0_bar.size();
+  res.initial_static_legal = calc_corridors(prob.x0_bar, prob.obstacles, prob.dimx, prob.dimy, prob.veh,
+                                            res.corridors, res.t_corridor_max);
+  res.solutions.assign(Na, {});
+  res.sqp_iters.assign(Na, 0);
+  res.admm_iters.assign(Na, 0);
+  res.last_status.assign(Na, 1);
+  res.agent_seconds.assign(Na, 0.0);
+  if (n_threads <= 1) {
+    for (int a = 0; a < Na; ++a) {
+      const auto t0 = clk::now();
+      individual_sqp(a, prob, res, trace);
+      res.agent_seconds[a] = secs_since(t0);
+    }
+  } else {
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int th = 0; th < n_threads; ++th)
+      pool.emplace_back([&]() {
+        for (;;) {
+          const int a = next.fetch_add(1);
+          if (a >= Na) break;
+          const auto t0 = clk::now();
+          individual_sqp(a, prob, res, nullptr);
+          res.agent_seconds[a] = secs_since(t0);
+        }
+      });
+    for (auto& t : pool) t.join();
+  }
+  // status aggregation, :1224-1243 (signed assignment quirk preserved)
+  bool any_bad = false;
+  int worst = 2;
+  for (int a = 0; a < Na; ++a) {
+    const int s = res.last_status[a];
+    if (std::abs(s) > 1) {
+      any_bad = true;
+      if (std::abs(s) > worst) worst = s;
+    }
+  }
+  res.solver_status = any_bad ? worst : 1;
+  res.t_max_individual = 0;
+  for (double s : res.agent_seconds) res.t_max_individual = std::max(res.t_max_individual, s);
+  res.t_max_individual += res.t_corridor_max;  // :1245-1248 (shared overhead is ~0 here)
+  res.t_total = secs_since(t_begin);
+}
+
+}  // namespace csdo_oracle

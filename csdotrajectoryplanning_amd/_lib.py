@@ -1,0 +1,59 @@
+"""ctypes binding of the shipped HIP library (libcsdo_hip.so).  There is no CPU fallback: if the library is missing
+or no HIP device is usable, the calls raise."""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsdo_hip.so")
+_LIB = None
+
+
+class CsdoError(RuntimeError):
+    pass
+
+
+_ERR = {abi.CSDO_EINVAL: "invalid argument", abi.CSDO_ENODEV: "no usable HIP device (MI355X required)",
+        abi.CSDO_ENOMEM: "allocation failed", abi.CSDO_ELIMIT: "problem exceeds a compiled limit (Nt > 512)",
+        abi.CSDO_EDEVICE: "HIP kernel launch or execution failed"}
+
+
+def check(rc, what):
+    if rc != abi.CSDO_OK:
+        raise CsdoError(f"{what} failed: {_ERR.get(rc, rc)} (code {rc})")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CsdoError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                            f"g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        H = C.c_void_p
+        L.csdo_backend_name.restype = C.c_char_p
+        L.csdo_dsqp_create.argtypes = [C.POINTER(H), C.c_int]
+        L.csdo_dsqp_destroy.argtypes = [H]
+        L.csdo_dsqp_destroy.restype = None
+        L.csdo_dsqp_solve.argtypes = [H, C.POINTER(abi.Problem), C.POINTER(abi.Result)]
+        L.csdo_dsqp_solve_batch.argtypes = [H, C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result)]
+        L.csdo_dsqp_upload.argtypes = [H, C.POINTER(abi.Problem), C.c_int32]
+        L.csdo_dsqp_run.argtypes = [H, C.c_void_p]
+        L.csdo_dsqp_download.argtypes = [H, C.POINTER(abi.Result), C.c_int32]
+        L.csdo_dsqp_last_kernel_seconds.argtypes = [H]
+        L.csdo_dsqp_last_kernel_seconds.restype = C.c_double
+        L.csdo_dsqp_device_solutions.argtypes = [H, C.POINTER(C.c_int64)]
+        L.csdo_dsqp_device_solutions.restype = C.c_void_p
+        L.csdo_preprocess.argtypes = [abi.c_double_p, abi.c_int32_p, abi.c_int32_p, C.c_int32, abi.c_double_p,
+                                      C.POINTER(abi.Vehicle), C.POINTER(abi.QpParm), C.POINTER(abi.BridgeOut)]
+        L.csdo_bridge_free.argtypes = [C.POINTER(abi.BridgeOut)]
+        L.csdo_bridge_free.restype = None
+        L.csdo_generate_boxes.argtypes = [H, abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
+                                          C.c_double, C.POINTER(abi.Vehicle), abi.c_double_p, abi.c_int32_p]
+        L.csdo_vehicle_default.argtypes = [C.POINTER(abi.Vehicle)]
+        L.csdo_vehicle_default.restype = None
+        L.csdo_qp_parm_default.argtypes = [C.POINTER(abi.Vehicle), C.POINTER(abi.QpParm)]
+        L.csdo_qp_parm_default.restype = None
+        _LIB = L
+    return _LIB

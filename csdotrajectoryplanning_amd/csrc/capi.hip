@@ -1,0 +1,295 @@
+// capi.hip — the C ABI of include/csdo_dsqp.h on top of the gfx950 kernels.
+// Host side only: packs the caller's buffers (batch_pack.h), owns device memory behind the handle, launches
+// dsqp_agent_kernel on the handle's (or the caller's) HIP stream and measures it with HIP events.
+// There is no CPU fallback: without a usable HIP device every entry point returns CSDO_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/csdo_dsqp.h"
+#include "batch_pack.h"
+#include "bridge_host.h"
+#include "dsqp_launch.h"
+
+using namespace csdo;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap && p) return CSDO_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes < 256 ? 256 : bytes;
+    if (hipMalloc(&p, want) != hipSuccess) return CSDO_ENOMEM;
+    cap = want;
+    return CSDO_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct csdo_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  HostBatch hb;
+  bool uploaded = false;
+  int n_worlds = 0;
+  double last_kernel_s = 0.0;
+  DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks;
+  DevBuf box_pts, box_obs, box_out, box_status;
+  std::vector<double> h_sol, h_corr;
+  std::vector<int32_t> h_sqp, h_admm, h_stat, h_legal;
+  std::vector<int64_t> h_ticks;
+  DeviceBatch dev{};
+};
+
+#define HIP_OK(expr, code)                 \
+  do {                                     \
+    if ((expr) != hipSuccess) return code; \
+  } while (0)
+
+extern "C" {
+
+const char* csdo_backend_name(void) { return "hip-gfx950"; }
+
+int csdo_dsqp_create(csdo_handle* out, int device_ordinal) {
+  if (!out) return CSDO_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return CSDO_ENODEV;
+  HIP_OK(hipSetDevice(device_ordinal), CSDO_ENODEV);
+  csdo_handle h = new (std::nothrow) csdo_handle_s();
+  if (!h) return CSDO_ENOMEM;
+  h->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return CSDO_ENODEV;
+  }
+  *out = h;
+  return CSDO_OK;
+}
+
+void csdo_dsqp_destroy(csdo_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
+                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->box_pts, &h->box_obs,
+                    &h->box_out, &h->box_status})
+    b->release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
+  if (!h) return CSDO_EINVAL;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  h->uploaded = false;
+  int rc = pack_worlds(worlds, n_worlds, h->hb);
+  if (rc != CSDO_OK) return rc;
+  HostBatch& hb = h->hb;
+  const size_t Na = hb.agents.size();
+#define UP(buf, vec)                                                                                         \
+  do {                                                                                                       \
+    const size_t bytes = (vec).size() * sizeof((vec)[0]);                                                    \
+    if ((rc = h->buf.ensure(bytes)) != CSDO_OK) return rc;                                                   \
+    if (bytes) HIP_OK(hipMemcpyAsync(h->buf.p, (vec).data(), bytes, hipMemcpyHostToDevice, h->stream), CSDO_EDEVICE); \
+  } while (0)
+  UP(agents, hb.agents);
+  UP(worlds, hb.worlds);
+  UP(x0, hb.x0);
+  UP(planes, hb.planes);
+  UP(tstart, hb.tstart);
+  UP(obstacles, hb.obstacles);
+#undef UP
+  if ((rc = h->rows_ws.ensure((size_t)hb.rows_total * ROWS_WS_STRIDE * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->fac_ws.ensure((size_t)hb.fac_total * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->sol.ensure((size_t)hb.steps_total * 6 * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->corr.ensure((size_t)hb.steps_total * 8 * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->sqp.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+  if ((rc = h->admm.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+  if ((rc = h->stat.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+  if ((rc = h->legal.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+  if ((rc = h->ticks.ensure(Na * sizeof(int64_t))) != CSDO_OK) return rc;
+  DeviceBatch& B = h->dev;
+  B.agents = (const AgentDesc*)h->agents.p;
+  B.worlds = (const WorldDesc*)h->worlds.p;
+  B.x0 = (const double*)h->x0.p;
+  B.planes = (const PlaneDev*)h->planes.p;
+  B.tstart = (const int32_t*)h->tstart.p;
+  B.obstacles = (const double*)h->obstacles.p;
+  B.rows_ws = (double*)h->rows_ws.p;
+  B.fac_ws = (double*)h->fac_ws.p;
+  B.sol = (double*)h->sol.p;
+  B.corr = (double*)h->corr.p;
+  B.sqp_iters = (int32_t*)h->sqp.p;
+  B.admm_iters = (int32_t*)h->admm.p;
+  B.last_status = (int32_t*)h->stat.p;
+  B.static_legal = (int32_t*)h->legal.p;
+  B.agent_ticks = (int64_t*)h->ticks.p;
+  B.n_agents = (int32_t)Na;
+  B.lds_fac = 0;
+  B.prm = hb.prm;
+  HIP_OK(hipStreamSynchronize(h->stream), CSDO_EDEVICE);
+  h->n_worlds = n_worlds;
+  h->uploaded = true;
+  return CSDO_OK;
+}
+
+int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
+  if (!h || !h->uploaded) return CSDO_EINVAL;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  HIP_OK(hipEventRecord(h->ev0, s), CSDO_EDEVICE);
+  if (launch_dsqp(h->dev, h->hb.max_nt, h->hb.max_obs, s) != hipSuccess) return CSDO_EDEVICE;
+  HIP_OK(hipEventRecord(h->ev1, s), CSDO_EDEVICE);
+  HIP_OK(hipEventSynchronize(h->ev1), CSDO_EDEVICE);
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1), CSDO_EDEVICE);
+  h->last_kernel_s = (double)ms * 1e-3;
+  return CSDO_OK;
+}
+
+double csdo_dsqp_last_kernel_seconds(csdo_handle h) { return h ? h->last_kernel_s : 0.0; }
+
+void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles) {
+  if (!h || !h->uploaded) return nullptr;
+  if (n_doubles) *n_doubles = h->hb.steps_total * 6;
+  return h->sol.p;
+}
+
+int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
+  if (!h || !h->uploaded || !results || n_worlds != h->n_worlds) return CSDO_EINVAL;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  const HostBatch& hb = h->hb;
+  const size_t Na = hb.agents.size();
+  h->h_sol.resize((size_t)hb.steps_total * 6);
+  h->h_corr.resize((size_t)hb.steps_total * 8);
+  h->h_sqp.resize(Na);
+  h->h_admm.resize(Na);
+  h->h_stat.resize(Na);
+  h->h_legal.resize(Na);
+  h->h_ticks.resize(Na);
+  hipStream_t s = h->stream;
+  HIP_OK(hipMemcpyAsync(h->h_sol.data(), h->sol.p, h->h_sol.size() * sizeof(double), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->h_corr.data(), h->corr.p, h->h_corr.size() * sizeof(double), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->h_sqp.data(), h->sqp.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->h_admm.data(), h->admm.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->h_stat.data(), h->stat.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->h_legal.data(), h->legal.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->h_ticks.data(), h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
+  unpack_results(hb, nullptr, n_worlds, h->h_sol.data(), h->h_corr.data(), h->h_sqp.data(), h->h_admm.data(),
+                 h->h_stat.data(), h->h_legal.data(), results);
+  for (int w = 0; w < n_worlds; ++w) {
+    int64_t mx = 0;
+    for (int a = hb.world_first_agent[w]; a < hb.world_first_agent[w + 1]; ++a) mx = std::max(mx, h->h_ticks[a]);
+    results[w].t_max_individual = (double)mx * 1e-8;  // wall_clock64 ticks at 100 MHz
+    results[w].t_device = h->last_kernel_s;
+  }
+  return CSDO_OK;
+}
+
+int csdo_dsqp_solve_batch(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds, csdo_result* results) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = csdo_dsqp_upload(h, worlds, n_worlds);
+  if (rc != CSDO_OK) return rc;
+  if ((rc = csdo_dsqp_run(h, nullptr)) != CSDO_OK) return rc;
+  if ((rc = csdo_dsqp_download(h, results, n_worlds)) != CSDO_OK) return rc;
+  const double tt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int w = 0; w < n_worlds; ++w) results[w].t_total = tt;
+  return CSDO_OK;
+}
+
+int csdo_dsqp_solve(csdo_handle h, const csdo_problem* in, csdo_result* out) {
+  if (!in || !out) return CSDO_EINVAL;
+  return csdo_dsqp_solve_batch(h, in, 1, out);
+}
+
+int csdo_generate_boxes(csdo_handle h, const double* points_xy, int32_t n, const double* obstacles, int32_t n_obs,
+                        double dimx, double dimy, const csdo_vehicle* veh, double* boxes, int32_t* status) {
+  if (!h || !points_xy || !veh || !boxes || !status || n < 0 || n_obs < 0 || (n_obs > 0 && !obstacles))
+    return CSDO_EINVAL;
+  if (n == 0) return CSDO_OK;
+  if ((size_t)3 * n_obs * sizeof(double) > 60 * 1024) return CSDO_ELIMIT;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  int rc;
+  if ((rc = h->box_pts.ensure((size_t)n * 2 * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->box_obs.ensure((size_t)n_obs * 3 * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->box_out.ensure((size_t)n * 4 * sizeof(double))) != CSDO_OK) return rc;
+  if ((rc = h->box_status.ensure((size_t)n * sizeof(int32_t))) != CSDO_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_OK(hipMemcpyAsync(h->box_pts.p, points_xy, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  if (n_obs)
+    HIP_OK(hipMemcpyAsync(h->box_obs.p, obstacles, (size_t)n_obs * 3 * sizeof(double), hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  if (launch_boxes((const double*)h->box_pts.p, n, (const double*)h->box_obs.p, n_obs, dimx, dimy, veh->rv,
+                   (double*)h->box_out.p, (int*)h->box_status.p, s) != hipSuccess)
+    return CSDO_EDEVICE;
+  HIP_OK(hipMemcpyAsync(boxes, h->box_out.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(status, h->box_status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
+  return CSDO_OK;
+}
+
+int csdo_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                    const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out) {
+  return bridge_preprocess(states, actions, path_off, Na, goals, veh, parm, out);
+}
+
+void csdo_bridge_free(csdo_bridge_out* out) { bridge_free(out); }
+
+void csdo_vehicle_default(csdo_vehicle* v) {
+  if (!v) return;
+  // config.yaml:4-27 through readAgentConfig (common/motion_planning.cc:64-85): YAML doubles stored in floats
+  const float r = 3.0f, deltat = 0.706f, W = 2.0f, LF = 2.0f, LB = 1.0f, WB = 1.0f, obsR = 0.8f;
+  const float f2x = (float)(1 / 4.0 * (3.0 * LF - LB));
+  const float r2x = (float)(1 / 4.0 * (LF - 3.0 * LB));
+  const float rv = (float)(1.0 / 2.0 * std::pow(std::pow(LF + LB, 2) / 4 + W * W, 0.5));
+  v->r = r;
+  v->deltat = deltat;
+  v->LF = LF;
+  v->LB = LB;
+  v->car_width = W;
+  v->WB = WB;
+  v->f2x = f2x;
+  v->r2x = r2x;
+  v->rv = rv;
+  v->obs_radius = obsR;
+}
+
+void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p) {
+  if (!v || !p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->r_trust = 2.0;
+  p->max_omega = 0.07;
+  p->max_v = 1.0;
+  p->max_iter = 10;
+  p->delta_solution_threshold = 1.0;
+  p->max_violation = 0.001;
+  p->osqp_max_iter = 400;
+  p->num_interpolation = 2;
+  const float step = (float)v->r * (float)v->deltat;  // sqp/utils.cc:55-56: float product, double divisions
+  p->dt = step / p->max_v / (p->num_interpolation + 1) / 0.8;
+  p->fixed_corridor = 0;
+  p->adaptive_rho_interval = 25;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Plain-old-data descriptors shared by the host launcher and the device lane program.
+// Layout in HBM (all fp64 unless noted), one launch = a batch of agents, one workgroup per agent:
+//   x0        [sum_a Nt_a][6]     initial guess x,y,yaw,steer,v,d_steer          (read once per agent)
+//   planes    [sum_a K_a]         {t, c[12]} per agent, t ascending               (read once per SQP iteration)
+//   tstart    [sum_a (Nt_a+1)]    CSR offsets of an agent's planes by timestep    (int32)
+//   obstacles [sum_w n_obs_w][3]  per world                                       (staged into LDS)
+//   rows_ws   [sum_a 4K_a][8]     inter-vehicle row state (y,z,u,E,ca,cb,cyaw,dy) (L2-resident working set)
+//   fac_ws    [sum_a 211*Nt_a]    BCR coupling blocks (when not in LDS) + factor exchange + cold per-lane data
+//   sol       [sum_a Nt_a][6], corr [sum_a Nt_a][8], per-agent counters           (written once per agent)
+#pragma once
+#include <cstdint>
+
+namespace csdo {
+
+struct AgentDesc {
+  int32_t Nt;          // horizon of this agent's world
+  int32_t world;       // index into WorldDesc
+  int32_t n_planes;    // K_a
+  int32_t _pad;
+  int64_t x0_off;      // element offset of x0[Nt][6] (in doubles)
+  int64_t plane_off;   // first plane of this agent
+  int64_t tstart_off;  // offset of tstart[Nt+1]
+  int64_t rows_off;    // first inter row (4 per plane) in rows_ws, in rows
+  int64_t fac_off;     // offset into fac_ws (doubles)
+  int64_t out_off;     // timestep offset into sol / corr
+};
+
+struct WorldDesc {
+  double dimx, dimy;
+  int32_t obs_off, n_obs;
+};
+
+struct PlaneDev {  // mirrors csdo_plane
+  int32_t t, _pad;
+  double c[12];
+};
+
+struct SolverParams {
+  // vehicle (float-rounded values widened to double; common/motion_planning.h:12-49 of the reference)
+  double f2x, r2x, rv, WB, r_turn;
+  // QpParm (sqp/common.h:39-52)
+  double r_trust, max_omega, max_v, delta_solution_threshold, dt;
+  int32_t max_iter, osqp_max_iter, fixed_corridor, adaptive_rho_interval;
+  // OSQP 0.6.3 defaults (osqp_set_default_settings)
+  double rho0, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
+  int32_t scaling_passes, check_termination;
+  double adaptive_rho_tolerance;
+};
+
+struct DeviceBatch {
+  const AgentDesc* agents;
+  const WorldDesc* worlds;
+  const double* x0;
+  const PlaneDev* planes;
+  const int32_t* tstart;
+  const double* obstacles;
+  double* rows_ws;
+  double* fac_ws;
+  double* sol;
+  double* corr;
+  int32_t* sqp_iters;
+  int32_t* admm_iters;
+  int32_t* last_status;
+  int32_t* static_legal;   // per agent: 1 if every initial box was legal
+  int64_t* agent_ticks;    // per agent device time, 100 MHz ticks
+  int32_t n_agents;
+  int32_t lds_fac;         // 1: coupling blocks live in LDS, 0: in fac_ws
+  SolverParams prm;
+};
+
+constexpr int ROWS_WS_STRIDE = 8;   // doubles per inter row in rows_ws
+constexpr int FAC_E_DOUBLES = 72;   // E_l + E_r per node
+constexpr int FAC_X_DOUBLES = 78;   // factor-time exchange per node: U_l(21) + U_r(21) + Rnew(36)
+constexpr int COLD_DOUBLES = 61;    // cold per-lane slots (ColdSlot in dsqp_program.h)
+
+}  // namespace csdo

@@ -1,0 +1,100 @@
+// dsqp_kernel.hip — gfx950 kernels of the DO backend.
+//   dsqp_agent_kernel<BLOCK>: one workgroup per agent runs the whole per-agent SQP (dsqp_program.h) start to
+//     finish; grid = number of agents in the batch; no host round trips, no inter-workgroup communication
+//     (agents are independent once the separating planes are fixed, sqp/dsqp_solver.cc:1198-1205).
+//   box_kernel: one lane per point, safe boxes for arbitrary points (csdo_generate_boxes).
+#define CSDO_LANE_MODE_DEVICE 1
+#include "dsqp_program.h"
+#include "dsqp_launch.h"
+
+namespace csdo {
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, const int max_obs) {
+  extern __shared__ __align__(16) double lds[];
+  const int agent = (int)blockIdx.x;
+  if (agent >= B.n_agents) return;
+  const long long t_begin = wall_clock64();
+  const AgentDesc& ad = B.agents[agent];
+  const int st = (ad.Nt + 1) & ~1;
+  Shm sh;
+  sh.stride = st;
+  sh.vec = lds;
+  sh.pl = sh.vec + 6 * st;
+  sh.pr = sh.pl + 6 * st;
+  sh.carry = sh.pr + 6 * st;
+  sh.carry2 = sh.carry + 6 * st;
+  sh.obs = sh.carry2 + 6 * st;
+  sh.bcast = sh.obs + 3 * max_obs;
+  double* fac_global = B.fac_ws + ad.fac_off;
+  sh.facE = B.lds_fac ? (sh.bcast + 32) : fac_global;
+  sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;
+  sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
+  LaneState lanes;
+  ProgramOut po;
+  agent_program(B, agent, sh, lanes, po);
+  if (threadIdx.x == 0) {
+    B.sqp_iters[agent] = po.sqp_iters;
+    B.admm_iters[agent] = po.admm_iters;
+    B.last_status[agent] = po.last_status;
+    B.static_legal[agent] = po.static_legal;
+    B.agent_ticks[agent] = wall_clock64() - t_begin;
+  }
+}
+
+__global__ void box_kernel(const double* __restrict__ pts, int n, const double* __restrict__ obs_aos, int n_obs,
+                           double dimx, double dimy, double rv, double* __restrict__ boxes,
+                           int* __restrict__ status) {
+  extern __shared__ __align__(16) double lds[];
+  for (int k = (int)threadIdx.x; k < n_obs; k += (int)blockDim.x) {
+    lds[k] = obs_aos[3 * k];
+    lds[n_obs + k] = obs_aos[3 * k + 1];
+    lds[2 * n_obs + k] = obs_aos[3 * k + 2];
+  }
+  __syncthreads();
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  BoxD b{0, 0, 0, 0};
+  status[i] = make_box(pts[2 * i], pts[2 * i + 1], lds, n_obs, dimx, dimy, rv, b);
+  boxes[4 * i] = b.x_min;
+  boxes[4 * i + 1] = b.y_min;
+  boxes[4 * i + 2] = b.x_max;
+  boxes[4 * i + 3] = b.y_max;
+}
+
+size_t dsqp_lds_bytes(int max_nt, int max_obs, bool lds_fac) {
+  const int st = (max_nt + 1) & ~1;
+  size_t d = (size_t)30 * st + (size_t)3 * max_obs + 32;
+  if (lds_fac) d += (size_t)FAC_E_DOUBLES * st;
+  return d * sizeof(double);
+}
+
+hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, hipStream_t stream) {
+  constexpr size_t LDS_CAP = 160 * 1024;
+  DeviceBatch b = B;
+  b.lds_fac = dsqp_lds_bytes(max_nt, max_obs, true) <= LDS_CAP ? 1 : 0;
+  const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, b.lds_fac != 0);
+  if (bytes > LDS_CAP) return hipErrorInvalidValue;
+  hipError_t e;
+  if (max_nt <= 256) {
+    e = hipFuncSetAttribute((const void*)dsqp_agent_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dsqp_agent_kernel<256>, dim3(b.n_agents), dim3(256), bytes, stream, b, max_obs);
+  } else {
+    e = hipFuncSetAttribute((const void*)dsqp_agent_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dsqp_agent_kernel<512>, dim3(b.n_agents), dim3(512), bytes, stream, b, max_obs);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,
+                        double* boxes, int* status, hipStream_t stream) {
+  const int block = 64;
+  const int grid = (n + block - 1) / block;
+  hipLaunchKernelGGL(box_kernel, dim3(grid), dim3(block), (size_t)3 * n_obs * sizeof(double), stream, pts, n, obs,
+                     n_obs, dimx, dimy, rv, boxes, status);
+  return hipGetLastError();
+}
+
+}  // namespace csdo

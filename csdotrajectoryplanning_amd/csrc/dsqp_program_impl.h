@@ -1,0 +1,986 @@
+// dsqp_program_impl.h — body of csdo::agent_program (see dsqp_program.h for the design).
+// Included only from dsqp_program.h.
+#pragma once
+
+namespace csdo {
+
+#define SH(arr, k, t) sh.arr[(k) * sh.stride + (t)]
+#define CD(slot, t) sh.cold[(slot) * sh.stride + (t)]
+
+// ---------------------------------------------------------------------------------------------------------
+// Assembly of the home rows of timestep t at the linearisation point S.sol0 (unscaled values).
+// Reference: calcKineConstraint :646-744, calcCfgConstraint :746-788, calcCorridorConstraint :874-968,
+// calcTrustRegionConstraint :970-994, calcMaxCtrlAndSteerConstraint :996-1039, objective :163-197.
+// ---------------------------------------------------------------------------------------------------------
+CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, const SolverParams& P, double& dyaw_f_x,
+                                double& dyaw_f_y, double& dyaw_r_x, double& dyaw_r_y, double& e_xf, double& e_yf,
+                                double& e_xr, double& e_yr) {
+  const int Nm = Nt - 1;
+  const double dt = P.dt, WB = P.WB;
+  const double yaw = CD(C_SOL0 + 2, t), st = CD(C_SOL0 + 3, t), v = CD(C_SOL0 + 4, t);
+  const double xt = CD(C_XT, t), yt = CD(C_YT, t), yawt = CD(C_YAWT, t);
+  const double sy = sin(yaw), cy = cos(yaw);
+  CSDO_FOR(i, NROW, {
+    CSDO_FOR(s, 3, { S.c[i][s] = 0.0; });
+    S.lo[i] = 0.0;
+    S.hi[i] = 0.0;
+    CD(C_E + i, t) = 1.0;
+  });
+  CSDO_FOR(i, 4, { S.cn[i] = 0.0; });
+  unsigned act = 0x0780u | 0x1800u | 0x8000u;  // corridor, trust, steer rows exist at every t
+  if (t < Nm) {
+    act |= ROWS_KIN | ROWS_CTRL;
+    const double cst = cos(st);
+    const double cst2 = cst * cst;  // (steer.cos()).pow(2)
+    // x-dyn
+    S.c[0][0] = 1.0;
+    S.c[0][1] = -dt * (v * sy);
+    S.c[0][2] = dt * cy;
+    S.cn[0] = -1.0;
+    S.lo[0] = S.hi[0] = -(dt * yaw * v * sy);
+    // y-dyn
+    S.c[1][0] = 1.0;
+    S.c[1][1] = dt * (v * cy);
+    S.c[1][2] = dt * sy;
+    S.cn[1] = -1.0;
+    S.lo[1] = S.hi[1] = -(-dt * yaw * v * cy);
+    // yaw-dyn
+    S.c[2][0] = 1.0;
+    S.c[2][1] = (dt / WB * v) / cst2;
+    S.c[2][2] = dt / WB * tan(st);
+    S.cn[2] = -1.0;
+    S.lo[2] = S.hi[2] = -(-dt * (st * v / WB / cst2));
+    // steer-dyn
+    S.c[3][0] = 1.0;
+    S.c[3][1] = dt * 1.0;
+    S.cn[3] = -1.0;
+    S.lo[3] = S.hi[3] = -0.0;
+    // control boxes
+    S.c[13][0] = 1.0;
+    S.lo[13] = -P.max_v;
+    S.hi[13] = P.max_v;
+    S.c[14][0] = 1.0;
+    S.lo[14] = -P.max_omega;
+    S.hi[14] = P.max_omega;
+  }
+  if (t == 0 || t == Nm) {  // start / goal pose pinned to the ORIGINAL initial guess
+    act |= ROWS_CFG;
+    S.c[4][0] = 1.0;
+    S.lo[4] = S.hi[4] = xt;
+    S.c[5][0] = 1.0;
+    S.lo[5] = S.hi[5] = yt;
+    S.c[6][0] = 1.0;
+    S.lo[6] = S.hi[6] = yawt;
+  }
+  // corridor rows: disc-centre linearisation
+  dyaw_f_x = -P.f2x * sy;
+  dyaw_f_y = P.f2x * cy;
+  dyaw_r_x = -P.r2x * sy;
+  dyaw_r_y = P.r2x * cy;
+  e_xf = P.f2x * (cy + yaw * sy);
+  e_yf = P.f2x * (sy - yaw * cy);
+  e_xr = P.r2x * (cy + yaw * sy);
+  e_yr = P.r2x * (sy - yaw * cy);
+  S.c[7][0] = 1.0;  S.c[7][1] = dyaw_f_x;  S.lo[7] = CD(C_CLB + 0, t) - e_xf;  S.hi[7] = CD(C_CUB + 0, t) - e_xf;
+  S.c[8][0] = 1.0;  S.c[8][1] = dyaw_f_y;  S.lo[8] = CD(C_CLB + 1, t) - e_yf;  S.hi[8] = CD(C_CUB + 1, t) - e_yf;
+  S.c[9][0] = 1.0;  S.c[9][1] = dyaw_r_x;  S.lo[9] = CD(C_CLB + 2, t) - e_xr;  S.hi[9] = CD(C_CUB + 2, t) - e_xr;
+  S.c[10][0] = 1.0; S.c[10][1] = dyaw_r_y; S.lo[10] = CD(C_CLB + 3, t) - e_yr; S.hi[10] = CD(C_CUB + 3, t) - e_yr;
+  // trust region around the original guess
+  S.c[11][0] = 1.0; S.lo[11] = -P.r_trust + xt; S.hi[11] = P.r_trust + xt;
+  S.c[12][0] = 1.0; S.lo[12] = -P.r_trust + yt; S.hi[12] = P.r_trust + yt;
+  // steer box
+  const double steer_max = atan(P.WB / P.r_turn);
+  S.c[15][0] = 1.0; S.lo[15] = -steer_max; S.hi[15] = steer_max;
+  S.act = act;
+  // objective: first-difference Laplacian on v (Neumann ends), identity on w
+  S.Pvv = (t < Nm) ? ((t == 0 || t == Nt - 2) ? 1.0 : 2.0) : 0.0;
+  S.Pvn = (t <= Nt - 3) ? -1.0 : 0.0;
+  S.Pww = (t < Nm) ? 1.0 : 0.0;
+  CSDO_FOR(j, 6, { CD(C_D + j, t) = 1.0; });
+}
+
+// =========================================================================================================
+template <class LaneStore>
+CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, LaneStore&& lanes,
+                           ProgramOut& out) {
+  const AgentDesc ad = B.agents[agent];
+  const WorldDesc wd = B.worlds[ad.world];
+  const SolverParams& P = B.prm;
+  const int Nt = ad.Nt, Nm = Nt - 1;
+  const double* x0g = B.x0 + ad.x0_off;
+  const PlaneDev* planes = B.planes + ad.plane_off;
+  const int32_t* tstart = B.tstart + ad.tstart_off;
+  double* rows = B.rows_ws + ad.rows_off * ROWS_WS_STRIDE;
+  const int n_obs = wd.n_obs;
+  const double dimx = wd.dimx, dimy = wd.dimy, rv = P.rv;
+  const bool has_inter = ad.n_planes > 0;
+  const double sigma = P.sigma, alpha = P.alpha;
+  const int n_vars = 6 * Nt - 2;
+
+#define ROW(r, f) rows[(int64_t)(r) * ROWS_WS_STRIDE + (f)]
+
+  // ---------------------------------------------------------------- phase 0: stage obstacles, load the guess
+  CSDO_LANES(t) {
+    for (int k = t; k < n_obs; k += Nt) {
+      const double* o = B.obstacles + (int64_t)(wd.obs_off + k) * 3;
+      sh.obs[k] = o[0];
+      sh.obs[n_obs + k] = o[1];
+      sh.obs[2 * n_obs + k] = o[2];
+    }
+    LaneState& S = CSDO_LS(t);
+    CSDO_FOR(k, 6, {
+      const double v = (t == Nm && k >= 4) ? 0.0 : x0g[(int64_t)t * 6 + k];
+      CD(C_SOL0 + k, t) = v;
+      CD(C_SOL + k, t) = v;
+    });
+    CD(C_XT, t) = x0g[(int64_t)t * 6 + 0];
+    CD(C_YT, t) = x0g[(int64_t)t * 6 + 1];
+    CD(C_YAWT, t) = x0g[(int64_t)t * 6 + 2];
+    S.ncols = (t < Nm) ? 6 : 4;
+    S.eqmask = 0;
+    S.loosemask = 0;
+  }
+  CSDO_SYNC();
+
+  // ---------------------------------------------------------------- initial corridors (calcCorridors :164-248)
+  // State's disc centres are float members (motion_planning.h:115-118,229-230): round through float here.
+  CSDO_LANES(t) {
+    const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
+    const double cy = cos(pyaw), sy = sin(pyaw);
+    const double xf = (double)(float)(px + P.f2x * cy), xr = (double)(float)(px + P.r2x * cy);
+    const double yf = (double)(float)(py + P.f2x * sy), yr = (double)(float)(py + P.r2x * sy);
+    BoxD bf, br;
+    const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+    const int sr = make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br);
+    CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min; CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
+    CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max; CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
+    const double part[1] = {((sf >> 1) > 0 || (sr >> 1) > 0) ? 1.0 : 0.0};
+    red_put<1>(sh, t, part);
+  }
+  {
+    double r[1];
+    red_fold<1, false>(sh, Nt, r);
+    out.static_legal = (r[0] > 0.0) ? 0 : 1;
+  }
+
+  const double th = P.delta_solution_threshold;
+  double delta = th + 1.0;
+  int it = 0, status = 1, admm_total = 0;
+
+  while (delta > th && it < P.max_iter) {
+    // ============================================================== assemble the QP (unscaled)
+    CSDO_MARK("assemble");
+    CSDO_LANES(t) {
+      LaneState& S = CSDO_LS(t);
+      double dfx, dfy, drx, dry, exf, eyf, exr, eyr;
+      assemble_home_rows(S, sh, t, Nt, P, dfx, dfy, drx, dry, exf, eyf, exr, eyr);
+      // inter-vehicle rows at t (calcInterVehicleConstraint :1097-1129): row = [a, b, a*Dx + b*Dy] on (x,y,yaw)_t,
+      // upper bound -(c + (a*Ex + b*Ey)), lower bound -inf
+      for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
+        const PlaneDev& pl = planes[k];
+        CSDO_FOR(r, 4, {
+          const double a = pl.c[3 * r], bb = pl.c[3 * r + 1], cc = pl.c[3 * r + 2];
+          const double Dx = (r < 2) ? dfx : drx, Dy = (r < 2) ? dfy : dry;
+          const double Ex = (r < 2) ? exf : exr, Ey = (r < 2) ? eyf : eyr;
+          const int rr = 4 * k + r;
+          ROW(rr, W_CA) = a;
+          ROW(rr, W_CB) = bb;
+          ROW(rr, W_CY) = a * Dx + bb * Dy;
+          ROW(rr, W_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
+          ROW(rr, W_E) = 1.0;
+        });
+      }
+    }
+
+    // ============================================================== Ruiz equilibration (scaling.c scale_data)
+    CSDO_MARK("ruiz");
+    double cscale = 1.0;
+    for (int pass = 0; pass < P.scaling_passes; ++pass) {
+      CSDO_LANES(t) {  // hand |cn| and |Pvn| to t+1
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(k, 4, { SH(carry, k, t) = fabs(S.cn[k]); });
+        SH(carry, 4, t) = fabs(S.Pvn);
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double cn_[6] = {0, 0, 0, 0, 0, 0};  // column norms of [P; A]
+        double* Dt = S.b;                    // scratch: per-column factor of this pass
+        double* Et = S.z;                    // scratch: per-row factor of this pass
+        if (t > 0) {
+          CSDO_FOR(k, 4, { cn_[k] = SH(carry, k, t - 1); });
+          cn_[4] = SH(carry, 4, t - 1);
+        }
+        cn_[4] = dmax(cn_[4], dmax(fabs(S.Pvv), fabs(S.Pvn)));
+        cn_[5] = dmax(cn_[5], fabs(S.Pww));
+        CSDO_FOR(i, NROW, {
+          double rn = 0.0;
+          if (S.act & (1u << i)) {
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) {
+                const double a = fabs(S.c[i][s]);
+                rn = dmax(rn, a);
+                cn_[row_col(i, s)] = dmax(cn_[row_col(i, s)], a);
+              }
+            });
+            if constexpr (i < 4) rn = dmax(rn, fabs(S.cn[i]));
+          }
+          Et[i] = 1.0 / sqrt(limit_scaling(rn));
+        });
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          cn_[0] = dmax(cn_[0], fabs(ROW(r, W_CA)));
+          cn_[1] = dmax(cn_[1], fabs(ROW(r, W_CB)));
+          cn_[2] = dmax(cn_[2], fabs(ROW(r, W_CY)));
+        }
+        CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_scaling(cn_[j])) : 1.0; });
+        // inter rows only touch own columns: scale them now
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          const double a = ROW(r, W_CA), bb = ROW(r, W_CB), cy = ROW(r, W_CY);
+          const double rn = dmax(dmax(fabs(a), fabs(bb)), fabs(cy));
+          const double et = 1.0 / sqrt(limit_scaling(rn));
+          ROW(r, W_CA) = (a * et) * Dt[0];
+          ROW(r, W_CB) = (bb * et) * Dt[1];
+          ROW(r, W_CY) = (cy * et) * Dt[2];
+          ROW(r, W_E) = ROW(r, W_E) * et;
+        }
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = Dt[k]; });
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        const double* Dt = S.b;
+        const double* Et = S.z;
+        double Dn[5] = {1, 1, 1, 1, 1};
+        if (t < Nm) CSDO_FOR(k, 5, { Dn[k] = SH(carry2, k, t + 1); });
+        CSDO_FOR(i, NROW, {
+          CSDO_FOR(s, 3, {
+            if constexpr (row_col(i, s) >= 0) S.c[i][s] = (S.c[i][s] * Et[i]) * Dt[row_col(i, s)];
+          });
+          if constexpr (i < 4) S.cn[i] = (S.cn[i] * Et[i]) * Dn[i];
+          CD(C_E + i, t) = CD(C_E + i, t) * Et[i];
+        });
+        // scaled |P(v_{t-1}, v_t)| as its owner computes it
+        double pvn_left = 0.0;
+        if (t > 0) pvn_left = (SH(carry, 4, t - 1) * SH(carry2, 4, t - 1)) * Dt[4];
+        S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
+        S.Pww = (S.Pww * Dt[5]) * Dt[5];
+        S.Pvn = (S.Pvn * Dt[4]) * Dn[4];
+        CSDO_FOR(j, 6, { CD(C_D + j, t) = CD(C_D + j, t) * Dt[j]; });
+        // cost normalisation: mean column norm of the scaled P
+        double colsum = 0.0;
+        if (t < Nm) colsum = dmax(dmax(fabs(S.Pvv), fabs(S.Pvn)), pvn_left) + fabs(S.Pww);
+        const double part[1] = {colsum};
+        red_put<1>(sh, t, part);
+      }
+      double r[1];
+      red_fold<1, true>(sh, Nt, r);
+      double c_temp = r[0] / (double)n_vars;
+      c_temp = osqp_max(c_temp, limit_scaling(0.0));  // ||q||_inf = 0 -> 1 (q = 0, :196-197)
+      c_temp = limit_scaling(c_temp);
+      c_temp = 1.0 / c_temp;
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        S.Pvv *= c_temp;
+        S.Pww *= c_temp;
+        S.Pvn *= c_temp;
+      }
+      cscale *= c_temp;
+    }
+    const double cinv = 1.0 / cscale;
+
+    // ============================================================== scaled bounds, row classes, warm start
+    CSDO_MARK("warmstart");
+    CSDO_LANES(t) {
+      LaneState& S = CSDO_LS(t);
+      unsigned eq = 0, loose = 0;
+      CSDO_FOR(i, NROW, {
+        if (S.act & (1u << i)) {
+          const double Ei = CD(C_E + i, t);
+          S.lo[i] = Ei * S.lo[i];
+          S.hi[i] = Ei * S.hi[i];
+          if (S.lo[i] < -OSQP_INFTY * MIN_SCALING && S.hi[i] > OSQP_INFTY * MIN_SCALING) loose |= 1u << i;
+          else if (S.hi[i] - S.lo[i] < RHO_TOL) eq |= 1u << i;
+        }
+      });
+      S.eqmask = eq;
+      S.loosemask = loose;
+      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) ROW(r, W_U) = ROW(r, W_E) * ROW(r, W_U);
+      // osqp_warm_start_x: x <- Dinv x0
+      CSDO_FOR(j, 6, { S.x[j] = (1.0 / CD(C_D + j, t)) * CD(C_SOL0 + j, t); });
+      CSDO_FOR(k, 4, { SH(carry2, k, t) = S.x[k]; });
+    }
+    CSDO_SYNC();
+    CSDO_LANES(t) {  // z <- A x, y <- 0
+      LaneState& S = CSDO_LS(t);
+      double xn[4] = {0, 0, 0, 0};
+      if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(carry2, k, t + 1); });
+      double Ax[NROW];
+      rows_times_x(S, S.x, xn, Ax);
+      CSDO_FOR(i, NROW, {
+        S.z[i] = Ax[i];
+        S.y[i] = 0.0;
+        CD(C_DY + i, t) = 0.0;
+      });
+      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+        ROW(r, W_Z) = (ROW(r, W_CA) * S.x[0] + ROW(r, W_CB) * S.x[1]) + ROW(r, W_CY) * S.x[2];
+        ROW(r, W_Y) = 0.0;
+        ROW(r, W_DY) = 0.0;
+      }
+    }
+
+    double rho = osqp_min(osqp_max(P.rho0, RHO_MIN), RHO_MAX);
+
+    // ============================================================== BCR factorisation of H = P + sigma I + A' R A
+    auto factor = [&](const double rho_now) __attribute__((always_inline)) {
+      CSDO_MARK("factor_begin");
+      const double rho_eq = RHO_EQ_OVER_RHO_INEQ * rho_now;
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? rho_of(S, k, rho_now) * S.cn[k] * S.cn[k] : 0.0; });
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double* A = S.fa;
+        double* R = S.fr;
+        CSDO_FOR(k, 21, { A[k] = 0.0; });
+        CSDO_FOR(k, 36, { R[k] = 0.0; });
+        CSDO_FOR(j, 6, { A[sym(j, j)] = (j < S.ncols) ? sigma : 1.0; });
+        A[sym(4, 4)] += S.Pvv;
+        A[sym(5, 5)] += S.Pww;
+        if (t > 0) CSDO_FOR(k, 4, { A[sym(k, k)] += SH(carry, k, t - 1); });
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            const double rh = rho_of(S, i, rho_now);
+            CSDO_FOR(s1, 3, {
+              if constexpr (row_col(i, s1) >= 0) {
+                const double rc = rh * S.c[i][s1];
+                CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, S.c[i][s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
+                if constexpr (i < 4) R[i * 6 + row_col(i, s1)] = fma(rc, S.cn[i], R[i * 6 + row_col(i, s1)]);
+              }
+            });
+          }
+        });
+        R[4 * 6 + 4] += S.Pvn;
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          const double a = ROW(r, W_CA), bb = ROW(r, W_CB), cy = ROW(r, W_CY);
+          // inter rows have l = -inf and finite u: never loose, never equality (u - l = inf)
+          A[sym(0, 0)] = fma(rho_now * a, a, A[sym(0, 0)]);
+          A[sym(1, 0)] = fma(rho_now * bb, a, A[sym(1, 0)]);
+          A[sym(1, 1)] = fma(rho_now * bb, bb, A[sym(1, 1)]);
+          A[sym(2, 0)] = fma(rho_now * cy, a, A[sym(2, 0)]);
+          A[sym(2, 1)] = fma(rho_now * cy, bb, A[sym(2, 1)]);
+          A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
+        }
+      }
+      (void)rho_eq;
+      for (int h = 1; h < Nt; h <<= 1) {
+        const int m2 = 2 * h - 1;
+        CSDO_LANES(t) {  // every active node publishes its coupling to the right neighbour
+          LaneState& S = CSDO_LS(t);
+          if ((t & (h - 1)) == 0) {
+            const bool has_r = (t + h) < Nt;
+            CSDO_FOR(k, 36, { SH(facE, 36 + k, t) = has_r ? S.fr[k] : 0.0; });
+          }
+        }
+        CSDO_SYNC();
+        CSDO_LANES(t) {  // eliminated nodes
+          LaneState& S = CSDO_LS(t);
+          if ((t & m2) == h) {
+            double Rl[36];
+            CSDO_FOR(k, 36, {
+              Rl[k] = SH(facE, 36 + k, t - h);
+              SH(facE, k, t) = Rl[k];
+            });
+            double Ain[21];
+            CSDO_FOR(k, 21, { Ain[k] = S.fa[k]; });
+            spd_inverse6(Ain, S.sinv);
+            // T = Sinv * Rl   (rows: own vars, cols: left node's vars)
+            double T[36];
+            CSDO_FOR(r, 6, {
+              CSDO_FOR(c, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(S.sinv[sym(r, k)], Rl[k * 6 + c], a); });
+                T[r * 6 + c] = a;
+              });
+            });
+            // U_l = Rl' T  -> Schur update of the left neighbour's diagonal block
+            CSDO_FOR(a_, 6, {
+              CSDO_FOR(b_, a_ + 1, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], T[k * 6 + b_], a); });
+                SH(facX, sym(a_, b_), t) = a;
+              });
+            });
+            if ((t + h) < Nt) {
+              const double* Rr = S.fr;
+              // V = Sinv * Rr'  (rows: own vars, cols: right node's vars)
+              double V[36];
+              CSDO_FOR(r, 6, {
+                CSDO_FOR(c, 6, {
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(S.sinv[sym(r, k)], Rr[c * 6 + k], a); });
+                  V[r * 6 + c] = a;
+                });
+              });
+              CSDO_FOR(a_, 6, {
+                CSDO_FOR(b_, a_ + 1, {
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], V[k * 6 + b_], a); });
+                  SH(facX, 21 + sym(a_, b_), t) = a;
+                });
+              });
+              // new coupling (right node <- left node) = -Rr * T
+              CSDO_FOR(a_, 6, {
+                CSDO_FOR(b_, 6, {
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], T[k * 6 + b_], a); });
+                  SH(facX, 42 + a_ * 6 + b_, t) = -a;
+                });
+              });
+            }
+          }
+        }
+        CSDO_SYNC();
+        CSDO_LANES(t) {  // remaining nodes absorb the Schur complements
+          LaneState& S = CSDO_LS(t);
+          if ((t & m2) == 0) {
+            if (t >= h) CSDO_FOR(k, 21, { S.fa[k] -= SH(facX, 21 + k, t - h); });
+            if ((t + h) < Nt) {
+              CSDO_FOR(k, 21, { S.fa[k] -= SH(facX, k, t + h); });
+              const bool has_rr = (t + 2 * h) < Nt;
+              CSDO_FOR(k, 36, { S.fr[k] = has_rr ? SH(facX, 42 + k, t + h) : 0.0; });
+            }
+          }
+        }
+      }
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        if (t == 0) {
+          double Ain[21];
+          CSDO_FOR(k, 21, { Ain[k] = S.fa[k]; });
+          spd_inverse6(Ain, S.sinv);
+        }
+      }
+      CSDO_SYNC();
+    };
+
+    // ============================================================== BCR solve: S.b (rhs) -> S.b (solution), also in sh.vec
+    auto solve = [&]() __attribute__((always_inline)) {
+      CSDO_MARK("solve_begin");
+      int htop = 1;
+      for (int h = 1; h < Nt; h <<= 1) {
+        const int m2 = 2 * h - 1;
+        htop = h;
+        CSDO_LANES(t) {
+          LaneState& S = CSDO_LS(t);
+          if (h > 1 && (t & (h - 1)) == 0) {  // absorb the partials of the previous level
+            const int hp = h >> 1;
+            if (t >= hp) CSDO_FOR(k, 6, { S.b[k] -= SH(pr, k, t - hp); });
+            if ((t + hp) < Nt) CSDO_FOR(k, 6, { S.b[k] -= SH(pl, k, t + hp); });
+          }
+          if ((t & m2) == h) {
+            double w[6];
+            symv6(S.sinv, S.b, w);
+            CSDO_FOR(k, 6, { S.b[k] = w[k]; });
+            CSDO_FOR(bcol, 6, {  // pl = E_l' w
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(SH(facE, k * 6 + bcol, t), w[k], a); });
+              SH(pl, bcol, t) = a;
+            });
+            if ((t + h) < Nt) {
+              CSDO_FOR(arow, 6, {  // pr = E_r w
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(SH(facE, 36 + arow * 6 + k, t), w[k], a); });
+                SH(pr, arow, t) = a;
+              });
+            }
+          }
+        }
+        CSDO_SYNC();
+      }
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        if (t == 0) {
+          if (htop < Nt) CSDO_FOR(k, 6, { S.b[k] -= SH(pl, k, htop); });
+          double w[6];
+          symv6(S.sinv, S.b, w);
+          CSDO_FOR(k, 6, {
+            S.b[k] = w[k];
+            SH(vec, k, 0) = w[k];
+          });
+        }
+      }
+      CSDO_SYNC();
+      for (int h = htop; h >= 1; h >>= 1) {
+        const int m2 = 2 * h - 1;
+        CSDO_LANES(t) {
+          LaneState& S = CSDO_LS(t);
+          if ((t & m2) == h) {
+            double xl[6], tmp[6];
+            CSDO_FOR(k, 6, { xl[k] = SH(vec, k, t - h); });
+            CSDO_FOR(r, 6, {
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(SH(facE, r * 6 + k, t), xl[k], a); });
+              tmp[r] = a;
+            });
+            if ((t + h) < Nt) {
+              double xr[6];
+              CSDO_FOR(k, 6, { xr[k] = SH(vec, k, t + h); });
+              CSDO_FOR(r, 6, {
+                double a = tmp[r];
+                CSDO_FOR(k, 6, { a = fma(SH(facE, 36 + k * 6 + r, t), xr[k], a); });
+                tmp[r] = a;
+              });
+            }
+            double corr[6];
+            symv6(S.sinv, tmp, corr);
+            CSDO_FOR(k, 6, {
+              S.b[k] = S.b[k] - corr[k];
+              SH(vec, k, t) = S.b[k];
+            });
+          }
+        }
+        CSDO_SYNC();
+      }
+    };
+
+    factor(rho);
+
+    // ============================================================== ADMM (osqp_solve, osqp.c)
+    const int max_it = P.osqp_max_iter;
+    const int chk = P.check_termination;
+    int iter = 0;
+    int qp_status = -10;  // OSQP_UNSOLVED
+    double nrm[12];       // last update_info: see the residual block below
+    CSDO_FOR(k, 12, { nrm[k] = 0.0; });
+    bool info_valid = false;
+
+    // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective
+    auto primal_infeasible = [&](const double eps_pinf) __attribute__((always_inline)) -> bool {
+      CSDO_MARK("pinf_begin");
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double nmax = 0.0;
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            double dyi = CD(C_DY + i, t);
+            if (S.hi[i] > OSQP_INFTY * MIN_SCALING) {
+              if (S.lo[i] < -OSQP_INFTY * MIN_SCALING) dyi = 0.0;
+              else dyi = osqp_min(dyi, 0.0);
+            } else if (S.lo[i] < -OSQP_INFTY * MIN_SCALING) {
+              dyi = osqp_max(dyi, 0.0);
+            }
+            CD(C_DY + i, t) = dyi;
+            nmax = dmax(nmax, fabs(CD(C_E + i, t) * dyi));
+          }
+        });
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {  // l = -inf, u finite
+          const double d = osqp_max(ROW(r, W_DY), 0.0);
+          ROW(r, W_DY) = d;
+          nmax = dmax(nmax, fabs(ROW(r, W_E) * d));
+        }
+        const double part[1] = {nmax};
+        red_put<1>(sh, t, part);
+      }
+      double r1[1];
+      red_fold<1, false>(sh, Nt, r1);
+      const double norm_dy = r1[0];
+      if (!(norm_dy > eps_pinf)) return false;
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double acc = 0.0;
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            const double dyi = CD(C_DY + i, t);
+            acc += S.hi[i] * osqp_max(dyi, 0.0) + S.lo[i] * osqp_min(dyi, 0.0);
+          }
+        });
+        // reference quirk: l = -infinity (a true IEEE inf, dsqp_solver.cc:1121-1123) times min(dy,0) = 0 is NaN, so
+        // the certificate test is false for every agent that has inter-vehicle rows; IEEE arithmetic reproduces it
+        const double ninf = -INFINITY;
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r)
+          acc += ROW(r, W_U) * osqp_max(ROW(r, W_DY), 0.0) + ninf * osqp_min(ROW(r, W_DY), 0.0);
+        const double part[1] = {acc};
+        red_put<1>(sh, t, part);
+      }
+      double r2[1];
+      red_fold<1, true>(sh, Nt, r2);
+      if (!(r2[0] < -eps_pinf * norm_dy)) return false;
+      // || Dinv A' dy ||
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * CD(C_DY + k, t) : 0.0; });
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        if (t > 0) CSDO_FOR(k, 4, { v[k] = SH(carry, k, t - 1); });
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            const double dyi = CD(C_DY + i, t);
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(S.c[i][s], dyi, v[row_col(i, s)]);
+            });
+          }
+        });
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          const double d = ROW(r, W_DY);
+          v[0] = fma(ROW(r, W_CA), d, v[0]);
+          v[1] = fma(ROW(r, W_CB), d, v[1]);
+          v[2] = fma(ROW(r, W_CY), d, v[2]);
+        }
+        double nmax = 0.0;
+        CSDO_FOR(j, 6, {
+          if (j < S.ncols) nmax = dmax(nmax, fabs((1.0 / CD(C_D + j, t)) * v[j]));
+        });
+        const double part[1] = {nmax};
+        red_put<1>(sh, t, part);
+      }
+      double r3[1];
+      red_fold<1, false>(sh, Nt, r3);
+      return r3[0] < eps_pinf * norm_dy;
+    };
+
+    // auxil.c check_termination on the residuals in nrm[]; returns true if a status was set
+    auto check_termination = [&](const bool approximate) __attribute__((always_inline)) -> bool {
+      double eps_abs = P.eps_abs, eps_rel = P.eps_rel, eps_pinf = P.eps_prim_inf;
+      const double pri_res = nrm[0], dua_res = cinv * nrm[6];
+      if (pri_res > OSQP_INFTY || dua_res > OSQP_INFTY) {
+        qp_status = -7;
+        return true;
+      }
+      if (approximate) {
+        eps_abs *= 10;
+        eps_rel *= 10;
+        eps_pinf *= 10;
+      }
+      const double eps_prim = eps_abs + eps_rel * osqp_max(nrm[1], nrm[2]);
+      bool prim_ok = false, prim_inf = false;
+      if (pri_res < eps_prim) prim_ok = true;
+      else prim_inf = primal_infeasible(eps_pinf);
+      double mx = osqp_max(0.0, nrm[7]);  // ||Dinv q|| = 0, then ||Dinv A'y||, then ||Dinv P x||
+      mx = osqp_max(mx, nrm[8]);
+      const double eps_dual = eps_abs + eps_rel * (mx * cinv);
+      const bool dual_ok = dua_res < eps_dual;
+      // dual infeasibility needs q'dx < 0; q = 0 in this problem family (:196-197), so it can never trigger
+      if (prim_ok && dual_ok) {
+        qp_status = approximate ? 2 : 1;
+        return true;
+      }
+      if (prim_inf) {
+        qp_status = approximate ? 3 : -3;
+        return true;
+      }
+      return false;
+    };
+
+    // update_info (auxil.c): residuals of the current (x, z, y), unscaled for the test and scaled for adapt_rho
+    auto update_info = [&]() __attribute__((always_inline)) {
+      CSDO_MARK("info_begin");
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = S.x[k]; });        // to t-1: x_{t+1} cols 0..3 and v_{t+1}
+        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * S.y[k] : 0.0; });  // to t+1: A'y share
+        SH(carry, 4, t) = S.x[4];
+        SH(carry, 5, t) = S.Pvn;
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double xn[4] = {0, 0, 0, 0};
+        double vn = 0.0, vp = 0.0, pvn_left = 0.0;
+        if (t < Nm) {
+          CSDO_FOR(k, 4, { xn[k] = SH(carry2, k, t + 1); });
+          vn = SH(carry2, 4, t + 1);
+        }
+        double Aty[6] = {0, 0, 0, 0, 0, 0};
+        if (t > 0) {
+          CSDO_FOR(k, 4, { Aty[k] = SH(carry, k, t - 1); });
+          vp = SH(carry, 4, t - 1);
+          pvn_left = SH(carry, 5, t - 1);
+        }
+        double Ax[NROW];
+        rows_times_x(S, S.x, xn, Ax);
+        double p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            const double einv = 1.0 / CD(C_E + i, t);
+            const double res = Ax[i] - S.z[i];
+            p[0] = dmax(p[0], fabs(einv * res));
+            p[1] = dmax(p[1], fabs(einv * S.z[i]));
+            p[2] = dmax(p[2], fabs(einv * Ax[i]));
+            p[3] = dmax(p[3], fabs(res));
+            p[4] = dmax(p[4], fabs(S.z[i]));
+            p[5] = dmax(p[5], fabs(Ax[i]));
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(S.c[i][s], S.y[i], Aty[row_col(i, s)]);
+            });
+          }
+        });
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          const double ca = ROW(r, W_CA), cb = ROW(r, W_CB), cy = ROW(r, W_CY);
+          const double ax = (ca * S.x[0] + cb * S.x[1]) + cy * S.x[2];
+          const double zz = ROW(r, W_Z), yy = ROW(r, W_Y), einv = 1.0 / ROW(r, W_E);
+          const double res = ax - zz;
+          p[0] = dmax(p[0], fabs(einv * res));
+          p[1] = dmax(p[1], fabs(einv * zz));
+          p[2] = dmax(p[2], fabs(einv * ax));
+          p[3] = dmax(p[3], fabs(res));
+          p[4] = dmax(p[4], fabs(zz));
+          p[5] = dmax(p[5], fabs(ax));
+          Aty[0] = fma(ca, yy, Aty[0]);
+          Aty[1] = fma(cb, yy, Aty[1]);
+          Aty[2] = fma(cy, yy, Aty[2]);
+        }
+        double Px[6] = {0, 0, 0, 0, 0, 0};
+        if (t < Nm) {
+          Px[4] = (S.Pvv * S.x[4] + S.Pvn * vn) + pvn_left * vp;
+          Px[5] = S.Pww * S.x[5];
+        }
+        CSDO_FOR(j, 6, {
+          if (j < S.ncols) {
+            const double dinv = 1.0 / CD(C_D + j, t);
+            const double dr = (0.0 + Px[j]) + Aty[j];
+            p[6] = dmax(p[6], fabs(dinv * dr));
+            p[7] = dmax(p[7], fabs(dinv * Aty[j]));
+            p[8] = dmax(p[8], fabs(dinv * Px[j]));
+            p[9] = dmax(p[9], fabs(dr));
+            p[10] = dmax(p[10], fabs(Aty[j]));
+            p[11] = dmax(p[11], fabs(Px[j]));
+          }
+        });
+        red_put<12>(sh, t, p);
+      }
+      red_fold<12, false>(sh, Nt, nrm);
+      info_valid = true;
+    };
+
+    bool can_check = false;
+    for (iter = 1; iter <= max_it; ++iter) {
+      // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
+    CSDO_MARK("rhs");
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(k, 4, {
+          SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_of(S, k, rho), S.z[k], -S.y[k]) : 0.0;
+        });
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double r6[6];
+        CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
+        if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            const double g = fma(rho_of(S, i, rho), S.z[i], -S.y[i]);
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) r6[row_col(i, s)] = fma(S.c[i][s], g, r6[row_col(i, s)]);
+            });
+          }
+        });
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          const double g = fma(rho, ROW(r, W_Z), -ROW(r, W_Y));
+          r6[0] = fma(ROW(r, W_CA), g, r6[0]);
+          r6[1] = fma(ROW(r, W_CB), g, r6[1]);
+          r6[2] = fma(ROW(r, W_CY), g, r6[2]);
+        }
+        CSDO_FOR(j, 6, { S.b[j] = r6[j]; });
+      }
+      solve();
+      // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
+    CSDO_MARK("update");
+      const bool keep_dy = (chk && (iter % chk == 0)) || iter == max_it;
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double xn[4] = {0, 0, 0, 0};
+        if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
+        double zt[NROW];
+        rows_times_x(S, S.b, xn, zt);
+        CSDO_FOR(i, NROW, {
+          if (S.act & (1u << i)) {
+            const double rh = rho_of(S, i, rho);
+            const double rinv = 1.0 / rh;
+            const double zr = alpha * zt[i] + (1.0 - alpha) * S.z[i];
+            const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], S.lo[i]), S.hi[i]);
+            const double d = rh * (zr - zn);
+            if (keep_dy) CD(C_DY + i, t) = d;
+            S.y[i] += d;
+            S.z[i] = zn;
+          }
+        });
+        const double rinv = 1.0 / rho;
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+          const double ztr = (ROW(r, W_CA) * S.b[0] + ROW(r, W_CB) * S.b[1]) + ROW(r, W_CY) * S.b[2];
+          const double zp = ROW(r, W_Z), yy = ROW(r, W_Y);
+          const double zr = alpha * ztr + (1.0 - alpha) * zp;
+          const double zn = osqp_min(zr + rinv * yy, ROW(r, W_U));  // lower bound is -inf
+          const double d = rho * (zr - zn);
+          if (keep_dy) ROW(r, W_DY) = d;
+          ROW(r, W_Y) = yy + d;
+          ROW(r, W_Z) = zn;
+        }
+        CSDO_FOR(j, 6, {
+          if (j < S.ncols) S.x[j] = alpha * S.b[j] + (1.0 - alpha) * S.x[j];
+        });
+      }
+      CSDO_SYNC();
+
+      can_check = chk && (iter % chk == 0);
+      info_valid = false;
+      if (__builtin_expect(can_check, 0)) {
+        update_info();
+        if (check_termination(false)) break;
+      }
+      if (__builtin_expect(P.adaptive_rho_interval && (iter % P.adaptive_rho_interval == 0) && iter < max_it, 0)) {
+        if (!info_valid) update_info();
+        // compute_rho_estimate (auxil.c), scaled residuals
+        double pri = nrm[3], dua = nrm[9];
+        const double pri_n = osqp_max(nrm[4], nrm[5]);
+        pri /= (pri_n + 1e-10);
+        double dua_n = osqp_max(0.0, nrm[10]);
+        dua_n = osqp_max(dua_n, nrm[11]);
+        dua /= (dua_n + 1e-10);
+        double est = rho * sqrt(pri / (dua + 1e-10));
+        est = osqp_min(osqp_max(est, RHO_MIN), RHO_MAX);
+        if (est > rho * P.adaptive_rho_tolerance || est < rho / P.adaptive_rho_tolerance) {
+          rho = osqp_min(osqp_max(est, RHO_MIN), RHO_MAX);
+          factor(rho);
+        }
+      }
+    }
+    if (iter > max_it) {
+      iter = max_it;
+      if (!can_check) {
+        update_info();
+        check_termination(false);
+      }
+    }
+    if (qp_status == -10) {
+      if (!check_termination(true)) qp_status = -2;  // OSQP_MAX_ITER_REACHED
+    }
+    status = qp_status;
+    admm_total += iter;
+
+    // ============================================================== SQP bookkeeping (calcIndividualSQP :223-253)
+    CSDO_MARK("bookkeeping");
+    CSDO_LANES(t) {
+      LaneState& S = CSDO_LS(t);
+      double acc = 0.0;
+      const bool keep_prev = (status > 2 || status < -2);  // :515-524
+      CSDO_FOR(j, 6, {
+        if (j < S.ncols) {
+          const double s0 = CD(C_SOL0 + j, t);
+          const double sn = keep_prev ? s0 : CD(C_D + j, t) * S.x[j];
+          CD(C_SOL + j, t) = sn;
+          const double d = sn - s0;
+          acc = fma(d, d, acc);
+        } else {
+          CD(C_SOL + j, t) = 0.0;
+        }
+      });
+      const double part[1] = {acc};
+      red_put<1>(sh, t, part);
+    }
+    {
+      double r[1];
+      red_fold<1, true>(sh, Nt, r);
+      delta = r[0];
+    }
+    it++;
+
+    bool feasible = false;
+    if (it > P.max_iter / 2) {  // isFeasible :292-420
+      CSDO_LANES(t) {
+        CSDO_FOR(k, 4, { SH(carry2, k, t) = CD(C_SOL + k, t); });
+      }
+      CSDO_SYNC();
+      CSDO_LANES(t) {
+        LaneState& S = CSDO_LS(t);
+        double p[6] = {0, 0, 0, 0, 0, 0};
+        const double x = CD(C_SOL + 0, t), y = CD(C_SOL + 1, t), yaw = CD(C_SOL + 2, t), stv = CD(C_SOL + 3, t),
+                     v = CD(C_SOL + 4, t), w = CD(C_SOL + 5, t);
+        if (t < Nm) {
+          const double r1 = x + v * cos(yaw) * P.dt - SH(carry2, 0, t + 1);
+          const double r2 = y + v * sin(yaw) * P.dt - SH(carry2, 1, t + 1);
+          const double r3 = yaw + v * tan(stv) / P.WB * P.dt - SH(carry2, 2, t + 1);
+          const double r4 = stv + w * P.dt - SH(carry2, 3, t + 1);
+          p[0] = r1 * r1;
+          p[1] = r2 * r2;
+          p[2] = r3 * r3;
+          p[3] = r4 * r4;
+        }
+        const double Y[4] = {x + P.f2x * cos(yaw), y + P.f2x * sin(yaw), x + P.r2x * cos(yaw), y + P.r2x * sin(yaw)};
+        double ecor = 0.0;
+        CSDO_FOR(k, 4, {
+          const double lbk = CD(C_CLB + k, t), ubk = CD(C_CUB + k, t);
+          if (!(lbk <= Y[k])) ecor = dmax(ecor, lbk - Y[k]);
+          if (!(Y[k] <= ubk)) ecor = dmax(ecor, Y[k] - ubk);
+        });
+        double eint = 0.0;
+        for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
+          const PlaneDev& pl = planes[k];
+          CSDO_FOR(r, 4, {
+            const double px = (r < 2) ? Y[0] : Y[2], py = (r < 2) ? Y[1] : Y[3];
+            const double res = ((0.0 + px * pl.c[3 * r]) + py * pl.c[3 * r + 1]) + pl.c[3 * r + 2];
+            if (res > 0) eint = dmax(eint, res);
+          });
+        }
+        p[4] = ecor;
+        p[5] = eint;
+        red_put<6>(sh, t, p);
+      }
+      double rs[4], rm[6];
+      // slots 0..3 are sums, 4..5 maxima: fold both ways and pick
+      {
+        double all_sum[6];
+        red_fold<6, true>(sh, Nt, all_sum);
+        CSDO_FOR(k, 4, { rs[k] = all_sum[k]; });
+      }
+      // the scratch still holds the partials (red_fold does not modify them)
+      red_fold<6, false>(sh, Nt, rm);
+      const double err_kin = (((rs[0] + rs[1]) + rs[2]) + rs[3]) / (double)Nt;
+      const double err_cor = rm[4];
+      const double err_int = has_inter ? rm[5] : 0.0;
+      feasible = (err_kin < 1e-2) && (err_int < 1e-1) && (err_cor < 1e-1);
+    }
+    if (feasible) break;
+
+    CSDO_LANES(t) {  // solution0 = solution; updateCorridor :818-872 (double-precision disc centres)
+      CSDO_FOR(k, 6, { CD(C_SOL0 + k, t) = CD(C_SOL + k, t); });
+      if (!P.fixed_corridor) {
+        const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
+        const double cy = cos(pyaw), sy = sin(pyaw);
+        const double xf = px + P.f2x * cy, xr = px + P.r2x * cy;
+        const double yf = py + P.f2x * sy, yr = py + P.r2x * sy;
+        BoxD bf, br;
+        make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+        make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br);
+        CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min; CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
+        CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max; CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- write results
+  CSDO_LANES(t) {
+    double* so = B.sol + (ad.out_off + t) * 6;
+    CSDO_FOR(k, 6, { so[k] = CD(C_SOL + k, t); });
+    double* co = B.corr + (ad.out_off + t) * 8;
+    CSDO_FOR(k, 4, {
+      co[2 * k] = CD(C_CLB + k, t);
+      co[2 * k + 1] = CD(C_CUB + k, t);
+    });
+  }
+  out.sqp_iters = it;
+  out.admm_iters = admm_total;
+  out.last_status = status;
+#undef ROW
+}
+
+#undef SH
+#undef CD
+
+}  // namespace csdo

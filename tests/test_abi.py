@@ -1,0 +1,64 @@
+"""The C-ABI library loads and exports every symbol include/csdo_dsqp.h declares; struct layouts match the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from csdotrajectoryplanning_amd import abi, config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "csdo_dsqp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(csdo_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_matches_symbol_list():
+    assert set(header_functions()) == set(abi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    from csdotrajectoryplanning_amd import _lib
+    L = _lib.lib()
+    for name in header_functions():
+        assert hasattr(L, name), name
+    assert L.csdo_backend_name() == b"hip-gfx950"
+
+
+def test_struct_layouts():
+    assert C.sizeof(abi.Plane) == 104
+    assert C.sizeof(abi.Vehicle) == 80
+    assert C.sizeof(abi.QpParm) == 6 * 8 + 2 * 4 + 8 + 2 * 4
+    assert abi.Problem.x0_bar.offset == 8 and abi.Problem.dimx.offset == 32
+    assert C.sizeof(abi.Result) == 5 * 8 + 2 * 4 + 3 * 8
+
+
+def test_defaults_match_reference_config_arithmetic():
+    from csdotrajectoryplanning_amd import _lib
+    v = abi.Vehicle()
+    _lib.lib().csdo_vehicle_default(C.byref(v))
+    p = abi.QpParm()
+    _lib.lib().csdo_qp_parm_default(C.byref(v), C.byref(p))
+    v2, p2 = config.vehicle_from_config(), config.qp_parm_from_config()
+    for f, _ in abi.Vehicle._fields_:
+        assert getattr(v, f) == getattr(v2, f), f
+    for f, _ in abi.QpParm._fields_:
+        assert getattr(p, f) == getattr(p2, f), f
+    # exact values of the float-derived constants
+    assert (v.f2x, v.r2x, v.rv) == (1.25, -0.25, 1.25)
+    assert p.dt == 0.8825000127156575
+    import numpy as np
+    assert float(np.float32(v.r) * np.float32(v.deltat)) == 2.118000030517578   # the float product r*deltat
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from csdotrajectoryplanning_amd import _lib
+    from csdotrajectoryplanning_amd.solver import DsqpHandle
+    with pytest.raises(_lib.CsdoError):
+        DsqpHandle(0)

@@ -1,0 +1,88 @@
+"""The device program (csrc/dsqp_program.h) compiled lane-serially for the host, against the oracle.  This is the
+CPU-side check of the host logic + program logic: structured assembly, Ruiz scaling with neighbour exchange, block
+cyclic reduction, ADMM, termination / adaptive rho, SQP control, corridor refresh.  The GPU tests run the same source as
+HIP device code."""
+import numpy as np
+import pytest
+
+from tests import helpers, parity
+
+
+def _check(ref, got):
+    c = parity.compare(ref, got)
+    assert c["counts_equal"], (ref.sqp_iters, got.sqp_iters, ref.admm_iters, got.admm_iters, ref.last_status,
+                               got.last_status)
+    assert not c["bad"], c["bad"]
+    assert ref.solver_status == got.solver_status and ref.initial_static_legal == got.initial_static_legal
+    return c
+
+
+@pytest.mark.parametrize("name", ["map50_agents0to5.npz", "map50_agents15to17.npz", "map100_agents0to3.npz"])
+def test_serial_program_matches_oracle_on_golden_inputs(oracle, emu, veh_parm, name):
+    veh, parm = veh_parm
+    world, z = helpers.load_golden(name, veh, parm)
+    got = emu.solve(world)
+    ref = oracle.solve(world, 2)
+    c = _check(ref, got)
+    # and directly against the committed golden outputs
+    assert np.array_equal(got.sqp_iters, z["sqp_iters"]) and np.array_equal(got.last_status, z["last_status"])
+    if c["n_flipped"] == 0:
+        np.testing.assert_allclose(got.solutions, z["solutions"], atol=parity.TOL, rtol=0)
+
+
+def test_fixed_corridor_mode_is_tight(oracle, emu, veh_parm):
+    """With the corridor refresh off (config fixed_corridor: true) there is no discontinuous box growth between SQP
+    iterations and the two implementations agree far below the 1e-4 bar."""
+    from csdotrajectoryplanning_amd import config
+    veh, _ = veh_parm
+    parm = config.qp_parm_from_config({"fixed_corridor": True})
+    world, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    ref, got = oracle.solve(world, 1), emu.solve(world)
+    assert np.array_equal(ref.sqp_iters, got.sqp_iters) and np.array_equal(ref.admm_iters, got.admm_iters)
+    np.testing.assert_allclose(got.solutions, ref.solutions, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(got.corridors, ref.corridors, atol=1e-12, rtol=0)
+
+
+def test_batch_of_worlds_equals_separate_solves(emu, veh_parm):
+    veh, parm = veh_parm
+    w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    w2, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)      # different Nt, obstacles, map size
+    both = emu.solve_batch([w1, w2])
+    for w, b in zip((w1, w2), both):
+        s = emu.solve(w)
+        assert np.array_equal(s.solutions, b.solutions) and np.array_equal(s.admm_iters, b.admm_iters)
+        assert s.solver_status == b.solver_status
+
+
+def test_edge_cases(oracle, emu, veh_parm):
+    veh, parm = veh_parm
+    # single agent, no obstacles, no planes, short horizon
+    w = helpers.straight_line_world(veh, parm, Na=1, L=2)
+    assert w.Nt == 7 and w.plane_off[-1] == 0
+    _check(oracle.solve(w, 1), emu.solve(w))
+    # two close agents: planes present at every step; one obstacle near the lane
+    w = helpers.straight_line_world(veh, parm, Na=2, L=5, spacing=3.5, obstacles=[[20.0, 16.5, 0.8]])
+    assert w.plane_off[-1] > 0
+    _check(oracle.solve(w, 1), emu.solve(w))
+    # the shortest legal horizon Nt = 2 through a hand-made world
+    import copy
+    w2 = copy.copy(w)
+    from csdotrajectoryplanning_amd.problem import World
+    w2 = World(w.x0_bar[:, :2].copy(), np.zeros(3, np.int32), w.planes[:0], w.dimx, w.dimy, w.obstacles, veh, parm)
+    _check(oracle.solve(w2, 1), emu.solve(w2))
+
+
+def test_corridor_boxes_bit_exact(oracle, emu, veh_parm):
+    """Corridor growth is pure compare/add arithmetic: on identical points the two implementations agree bit for bit."""
+    veh, parm = veh_parm
+    world, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-1, 101, (400, 2)), world.x0_bar[0, :, :2],
+                          world.obstacles[:, :2] + rng.uniform(-1.5, 1.5, (len(world.obstacles), 2))])
+    bo, so = oracle.generate_boxes(pts, world.obstacles, world.dimx, world.dimy, veh)
+    be, se = emu.generate_boxes(pts, world.obstacles, world.dimx, world.dimy, veh)
+    assert np.array_equal(so, se)
+    legal = (so >> 1) != 2            # the repair path calls atan2/cos/sin: compared with a tolerance below
+    assert np.array_equal(bo[legal], be[legal])
+    np.testing.assert_allclose(bo[~legal], be[~legal], atol=1e-9, rtol=0)
+    assert (~legal).sum() > 0 and ((so >> 1) == 1).sum() > 0

@@ -52,6 +52,7 @@ struct csdo_handle_s {
   double last_kernel_s = 0.0;
   DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks;
   DevBuf box_pts, box_obs, box_out, box_status;
+  DevBuf prof;
   std::vector<double> h_sol, h_corr;
   std::vector<int32_t> h_sqp, h_admm, h_stat, h_legal;
   std::vector<int64_t> h_ticks;
@@ -147,6 +148,11 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   B.agent_ticks = (int64_t*)h->ticks.p;
   B.n_agents = (int32_t)Na;
   B.lds_fac = 0;
+  B.prof = nullptr;
+#if defined(CSDO_PROFILE_PHASES)
+  if ((rc = h->prof.ensure(Na * 16 * sizeof(int64_t))) != CSDO_OK) return rc;
+  B.prof = (int64_t*)h->prof.p;
+#endif
   B.prm = hb.prm;
   HIP_OK(hipStreamSynchronize(h->stream), CSDO_EDEVICE);
   h->n_worlds = n_worlds;
@@ -291,5 +297,16 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p) {
   p->fixed_corridor = 0;
   p->adaptive_rho_interval = 25;
 }
+
+#if defined(CSDO_PROFILE_PHASES)
+// diagnostic build only (libcsdo_hip_prof.so): per-agent shader-clock ticks per phase and per-agent wall ticks
+int csdo_debug_phase_ticks(csdo_handle h, int64_t* phases16, int64_t* agent_ticks) {
+  if (!h || !h->uploaded) return CSDO_EINVAL;
+  const size_t Na = h->hb.agents.size();
+  if (hipMemcpy(phases16, h->prof.p, Na * 16 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
+  if (hipMemcpy(agent_ticks, h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
+  return CSDO_OK;
+}
+#endif
 
 }  // extern "C"

@@ -4,8 +4,8 @@
 //   planes    [sum_a K_a]         {t, c[12]} per agent, t ascending               (read once per SQP iteration)
 //   tstart    [sum_a (Nt_a+1)]    CSR offsets of an agent's planes by timestep    (int32)
 //   obstacles [sum_w n_obs_w][3]  per world                                       (staged into LDS)
-//   rows_ws   [sum_a 4K_a][8]     inter-vehicle row state (y,z,u,E,ca,cb,cyaw,dy) (L2-resident working set)
-//   fac_ws    [sum_a 211*Nt_a]    BCR coupling blocks (when not in LDS) + factor exchange + cold per-lane data
+//   rows_ws   [sum_a][8][4K_a]    inter-vehicle row state by field (y,z,dy | u,E,ca,cb,cyaw), L2-resident
+//   fac_ws    [sum_a 357*Nt_a]    BCR coupling blocks (when not in LDS) + factor exchange + per-lane workspace
 //   sol       [sum_a Nt_a][6], corr [sum_a Nt_a][8], per-agent counters           (written once per agent)
 #pragma once
 #include <cstdint>
@@ -64,13 +64,14 @@ struct DeviceBatch {
   int32_t* static_legal;   // per agent: 1 if every initial box was legal
   int64_t* agent_ticks;    // per agent device time, 100 MHz ticks
   int32_t n_agents;
-  int32_t lds_fac;         // 1: coupling blocks live in LDS, 0: in fac_ws
+  int32_t lds_fac;         // unused (coupling blocks are cached in solver-lane registers)
+  int64_t* prof;           // diagnostic builds only: [n_agents][16] shader-clock ticks per phase, else null
   SolverParams prm;
 };
 
 constexpr int ROWS_WS_STRIDE = 8;   // doubles per inter row in rows_ws
-constexpr int FAC_E_DOUBLES = 72;   // E_l + E_r per node
+constexpr int FAC_E_DOUBLES = 72;   // E_l + E_r per node, lane-major
 constexpr int FAC_X_DOUBLES = 78;   // factor-time exchange per node: U_l(21) + U_r(21) + Rnew(36)
-constexpr int COLD_DOUBLES = 61;    // cold per-lane slots (ColdSlot in dsqp_program.h)
+constexpr int COLD_DOUBLES = 210;   // per-lane workspace slots (WsSlot in dsqp_program.h)
 
 }  // namespace csdo

@@ -9,8 +9,10 @@
 
 namespace csdo {
 
+// BLOCK = 2 * (lanes per role): threads [0, BLOCK/2) are row lanes, [BLOCK/2, BLOCK) solver lanes (dsqp_program.h)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, const int max_obs) {
+  constexpr bool BIG = (BLOCK == 1024);  // Nt > 256: E_r and the bounds stay in the workspace, LDS holds vectors only
   extern __shared__ __align__(16) double lds[];
   const int agent = (int)blockIdx.x;
   if (agent >= B.n_agents) return;
@@ -22,23 +24,33 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   sh.vec = lds;
   sh.pl = sh.vec + 6 * st;
   sh.pr = sh.pl + 6 * st;
-  sh.carry = sh.pr + 6 * st;
-  sh.carry2 = sh.carry + 6 * st;
-  sh.obs = sh.carry2 + 6 * st;
+  sh.carry = sh.pl;     // aliases, see Shm
+  sh.carry2 = sh.pr;
+  sh.lohi = sh.pr + 6 * st;
+  sh.red = sh.lohi;                       // BIG: this region is only the 12-wide reduction scratch
+  sh.er = sh.lohi + 22 * st;
+  sh.obs = BIG ? (sh.red + 12 * st) : (sh.er + 36 * st);
   sh.bcast = sh.obs + 3 * max_obs;
   double* fac_global = B.fac_ws + ad.fac_off;
-  sh.facE = B.lds_fac ? (sh.bcast + 32) : fac_global;
+  sh.facE = fac_global;
   sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;
   sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
-  LaneState lanes;
   ProgramOut po;
-  agent_program(B, agent, sh, lanes, po);
-  if (threadIdx.x == 0) {
-    B.sqp_iters[agent] = po.sqp_iters;
-    B.admm_iters[agent] = po.admm_iters;
-    B.last_status[agent] = po.last_status;
-    B.static_legal[agent] = po.static_legal;
-    B.agent_ticks[agent] = wall_clock64() - t_begin;
+  if (threadIdx.x < BLOCK / 2) {        // row waves
+    RowRegs lr;
+    SolvRegs ls_unused;
+    agent_program<ROLE_ROW, BIG>(B, agent, sh, lr, ls_unused, po);
+    if (threadIdx.x == 0) {
+      B.sqp_iters[agent] = po.sqp_iters;
+      B.admm_iters[agent] = po.admm_iters;
+      B.last_status[agent] = po.last_status;
+      B.static_legal[agent] = po.static_legal;
+      B.agent_ticks[agent] = wall_clock64() - t_begin;
+    }
+  } else {                              // solver waves
+    RowRegs lr_unused;
+    SolvRegs ls;
+    agent_program<ROLE_SOLVER, BIG>(B, agent, sh, lr_unused, ls, po);
   }
 }
 
@@ -62,30 +74,29 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
   boxes[4 * i + 3] = b.y_max;
 }
 
-size_t dsqp_lds_bytes(int max_nt, int max_obs, bool lds_fac) {
+size_t dsqp_lds_bytes(int max_nt, int max_obs, bool) {
   const int st = (max_nt + 1) & ~1;
-  size_t d = (size_t)30 * st + (size_t)3 * max_obs + 32;
-  if (lds_fac) d += (size_t)FAC_E_DOUBLES * st;
-  return d * sizeof(double);
+  const size_t per_lane = (max_nt > 256) ? 30 : 76;   // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + er 36)
+  return (per_lane * st + (size_t)3 * max_obs + 32) * sizeof(double);
 }
 
 hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, hipStream_t stream) {
   constexpr size_t LDS_CAP = 160 * 1024;
   DeviceBatch b = B;
-  b.lds_fac = dsqp_lds_bytes(max_nt, max_obs, true) <= LDS_CAP ? 1 : 0;
-  const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, b.lds_fac != 0);
+  b.lds_fac = 0;
+  const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, false);
   if (bytes > LDS_CAP) return hipErrorInvalidValue;
-  hipError_t e;
-  if (max_nt <= 256) {
-    e = hipFuncSetAttribute((const void*)dsqp_agent_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  auto go = [&](auto kernel, int block) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dsqp_agent_kernel<256>, dim3(b.n_agents), dim3(256), bytes, stream, b, max_obs);
-  } else {
-    e = hipFuncSetAttribute((const void*)dsqp_agent_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dsqp_agent_kernel<512>, dim3(b.n_agents), dim3(512), bytes, stream, b, max_obs);
-  }
-  return hipGetLastError();
+    hipLaunchKernelGGL(kernel, dim3(b.n_agents), dim3(block), bytes, stream, b, max_obs);
+    return hipGetLastError();
+  };
+  // two lanes per timestep: Nt <= 128 -> 256 threads (512 registers per lane), <= 256 -> 512 threads (256 registers),
+  // <= 512 -> 1024 threads (128 registers: correct but spills; horizons that long are outside the benchmark sets)
+  if (max_nt <= 128) return go(dsqp_agent_kernel<256>, 256);
+  if (max_nt <= 256) return go(dsqp_agent_kernel<512>, 512);
+  return go(dsqp_agent_kernel<1024>, 1024);
 }
 
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,

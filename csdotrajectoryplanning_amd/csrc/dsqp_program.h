@@ -32,23 +32,48 @@
 #if defined(CSDO_LANE_MODE_DEVICE)
 #include <hip/hip_runtime.h>
 #define CSDO_FN __device__ __forceinline__
-#define CSDO_LANES(t) if (const int t = (int)threadIdx.x; t < Nt)
-#define CSDO_LS(t) lanes
+// Two specialised lanes per timestep: row lanes are threads [0, Nt), solver lanes are threads [HALF, HALF + Nt).
+// The program is instantiated once per role (ROLE_ROW for the first half of the workgroup, ROLE_SOLVER for the
+// second): blocks of the other role are compiled out, so each instantiation only carries its own register state.
+// Both instantiations execute the same barrier sequence and derive every uniform control value (iteration counts,
+// status, rho, norms) from the same LDS broadcasts.
+#define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = (int)threadIdx.x; t < Nt)
+#define CSDO_SLANES(t) \
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - (int)(blockDim.x >> 1); t >= 0 && t < Nt)
+#define CSDO_LS(t) lanes_r
+#define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
-#define CSDO_LANESTORE LaneState&
 #define CSDO_MARK(name) asm volatile("; CSDO_MARK " name)
+#if defined(CSDO_PROFILE_PHASES)
+// diagnostic build: thread 0 accumulates shader-clock ticks per phase (never enabled in the shipped library)
+#define CSDO_PHASE(k)                                                    \
+  do {                                                                   \
+    if (threadIdx.x == 0) {                                              \
+      const long long now_ = (long long)__builtin_amdgcn_s_memtime();    \
+      prof_acc[prof_cur] += now_ - prof_last;                            \
+      prof_last = now_;                                                  \
+      prof_cur = (k);                                                    \
+    }                                                                    \
+  } while (0)
+#else
+#define CSDO_PHASE(k) ((void)0)
+#endif
 #elif defined(CSDO_LANE_MODE_SERIAL)
 #define CSDO_FN inline
-#define CSDO_LANES(t) for (int t = 0; t < Nt; ++t)
-#define CSDO_LS(t) lanes[t]
+#define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)
+#define CSDO_SLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < Nt; ++t)
+#define CSDO_LS(t) lanes_r[t]
+#define CSDO_SS(t) lanes_s[t]
 #define CSDO_SYNC() ((void)0)
-#define CSDO_LANESTORE LaneState*
 #define CSDO_MARK(name) ((void)0)
+#define CSDO_PHASE(k) ((void)0)
 #else
 #error "define CSDO_LANE_MODE_DEVICE or CSDO_LANE_MODE_SERIAL"
 #endif
 
 namespace csdo {
+
+constexpr int ROLE_BOTH = 0, ROLE_ROW = 1, ROLE_SOLVER = 2;   // ROLE_BOTH: lane-serial host build
 
 // ---------------------------------------------------------------------------------------------------------
 // Row / column tables.  Home rows of timestep t (SURVEY Appendix A for the coefficients):
@@ -87,6 +112,7 @@ CSDO_FN double dmax(double a, double b) { return (b > a) ? b : a; }   // NaN in 
 CSDO_FN double dmin(double a, double b) { return (b < a) ? b : a; }
 CSDO_FN double osqp_max(double a, double b) { return (a > b) ? a : b; }  // c_max
 CSDO_FN double osqp_min(double a, double b) { return (a < b) ? a : b; }  // c_min
+CSDO_FN int osqp_min_i(int a, int b) { return (a < b) ? a : b; }
 CSDO_FN double limit_scaling(double d) {
   d = d < MIN_SCALING ? 1.0 : d;
   d = d > MAX_SCALING ? MAX_SCALING : d;
@@ -97,47 +123,70 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 // ---------------------------------------------------------------------------------------------------------
 // Per-lane state (registers on the device)
 // ---------------------------------------------------------------------------------------------------------
-struct LaneState {          // ADMM-hot state: stays in registers for the whole QP
+// Register state of the two lane roles (each program instantiation only ever touches its own).  Both are caches of the per-agent workspace: loaded at the start of a block of <= check_termination ADMM iterations
+// and written back at its end; every cold phase works from the workspace with short-lived temporaries.
+struct RowRegs {            // row lane of timestep t: the 16 home constraint rows and the 6 variables
   double c[NROW][3];        // scaled coefficients on own columns
   double cn[4];             // scaled coefficient of kin rows on column i of t+1
   double lo[NROW], hi[NROW];// scaled bounds
   double y[NROW], z[NROW];  // ADMM dual / slack (z doubles as Ruiz scratch before the warm start)
   double x[6];              // scaled primal iterate
-  double b[6];              // rhs -> BCR work vector -> x_tilde
-  double Pvv, Pww, Pvn;     // scaled objective: diag v, diag w, coupling (v_t, v_{t+1})
-  double sinv[21];          // inverse of this node's BCR pivot block (symmetric, packed lower)
-  double fa[21], fr[36];    // factor-time only: current diagonal block and coupling to the right neighbour
+  double b[6];              // Ruiz scratch / rhs temporary
+  double Pvv, Pww, Pvn;     // scaled objective (set-up stage; kept in the workspace afterwards)
   unsigned eqmask;          // rows in OSQP's "equality" class (rho * 1e3)
   unsigned loosemask;       // rows with both bounds infinite (rho = RHO_MIN)
   unsigned act;             // rows that exist at this t
   int ncols;                // 6, or 4 at t = Nt-1
 };
+struct SolvRegs {           // solver lane of timestep t: BCR node t and the inter-vehicle rows at t
+  double sinv[21];          // inverse of this node's BCR pivot block (symmetric, packed lower)
+  double b[6];              // rhs -> BCR work vector -> x_tilde
+  double el[36];            // coupling block to the left neighbour at this node's elimination level (E_r: LDS)
+  double fa[21], fr[36];    // factor-time only: current diagonal block and coupling to the right neighbour
+};
+typedef RowRegs LaneState;  // the row lane is the "home" of a timestep
 
-// Cold per-lane data lives in a coalesced per-agent workspace [slot][stride] (HBM, L2-resident): touched once per
-// SQP iteration or once per termination check, never inside the ADMM iteration.
-enum ColdSlot {
-  C_E = 0,      // [16] Ruiz row scaling
-  C_D = 16,     // [6]  Ruiz column scaling
-  C_SOL0 = 22,  // [6]  previous SQP iterate == linearisation point (x,y,yaw,steer,v,w), unscaled
-  C_SOL = 28,   // [6]  latest QP solution, unscaled
-  C_XT = 34, C_YT = 35, C_YAWT = 36,  // original initial guess (trust centre, start/goal rows): never moved
-  C_CLB = 37,   // [4]  corridor of the linearisation point: xf, yf, xr, yr lower
-  C_CUB = 41,   // [4]  upper
-  C_DY = 45,    // [16] last y-increment, kept on termination-check iterations only
-  C_TOTAL = 61
+// Per-agent workspace in HBM (L2-resident), SoA [slot][stride]: the master copy of every per-lane quantity.
+enum WsSlot {
+  W_C = 0,      // [48] c[i][s] at 3*i+s
+  W_CN = 48,    // [4]
+  W_LO = 52,    // [16]
+  W_HI = 68,    // [16]
+  W_Yv = 84,    // [16]
+  W_Zv = 100,   // [16]
+  W_X = 116,    // [6]
+  W_SINV = 122, // [21]
+  W_P = 143,    // [3] Pvv, Pww, Pvn
+  C_E = 146,    // [16] Ruiz row scaling
+  C_D = 162,    // [6]  Ruiz column scaling
+  C_SOL0 = 168, // [6]  previous SQP iterate == linearisation point (x,y,yaw,steer,v,w), unscaled
+  C_SOL = 174,  // [6]  latest QP solution, unscaled
+  C_XT = 180, C_YT = 181, C_YAWT = 182,  // original initial guess (trust centre, start/goal rows): never moved
+  C_CLB = 183,  // [4]  corridor of the linearisation point: xf, yf, xr, yr lower
+  C_CUB = 187,  // [4]  upper
+  C_DY = 191,   // [16] last y-increment, kept on termination-check iterations only
+  W_ACT = 207, W_EQ = 208, W_LOOSE = 209,  // row masks as exactly-representable doubles (read by the solver lanes)
+  C_TOTAL = 210
 };
 
-// Shared (LDS) arrays, SoA with `stride` doubles per component
+// lane-major leading dimensions (doubles per lane) of the LDS arrays
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 36;
+
+// Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
-  double* vec;      // [6][stride]  x_tilde / x exchange
-  double* pl;       // [6][stride]  BCR partials for the left neighbour; aliases red[0..5]
-  double* pr;       // [6][stride]  BCR partials for the right neighbour; aliases red[6..11]
-  double* carry;    // [6][stride]  t -> t+1 hand-over (rhs, norms, scalings)
-  double* carry2;   // [6][stride]  t -> t-1 hand-over
+  double* vec;      // [stride][6]  rhs / x_tilde / x exchange
+  double* pl;       // [stride][6]  BCR partials for the left neighbour   (solve only)
+  double* pr;       // [stride][6]  BCR partials for the right neighbour  (solve only)
+  double* carry;    // [stride][6]  t -> t+1 hand-over; ALIASES pl (dead during the solve)
+  double* carry2;   // [stride][6]  t -> t-1 hand-over and inter-row rhs share; ALIASES pr
+  double* lohi;     // [stride][22] bounds of the home rows during an ADMM block: 0..6 eq rows (lo = hi),
+                    //              7..12 lo and 13..18 hi of corridor/trust rows, 19..21 hi of the +-boxes (lo = -hi)
+  double* red;      // [stride][12] reduction scratch; ALIASES lohi (reductions only run between ADMM blocks)
+  double* er;       // [stride][36] coupling block E_r of each BCR node (E_l sits in solver-lane registers)
   double* obs;      // [3][n_obs]
-  double* facE;     // [72][stride] coupling blocks (LDS or global)
-  double* facX;     // [78][stride] factor-time exchange (global)
-  double* cold;     // [C_TOTAL][stride] cold per-lane data (global)
+  double* facE;     // [stride][72] coupling blocks E_l (36) + E_r (36), lane-major (global; cached in solver registers)
+  double* facX;     // [78][stride] factor-time exchange (global, coalesced)
+  double* cold;     // [C_TOTAL][stride] per-agent workspace (global)
   double* bcast;    // [32] block-wide results
   int stride;
 };
@@ -152,8 +201,8 @@ struct AgentCtx {
   int n_obs;
 };
 
-// inter-row workspace accessors (AoS of 8 doubles per row)
-enum { W_Y = 0, W_Z = 1, W_U = 2, W_E = 3, W_CA = 4, W_CB = 5, W_CY = 6, W_DY = 7 };
+// inter-vehicle row workspace: SoA by field, [field][4K] per agent (the 4 rows of a plane are contiguous)
+enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };
 
 // =========================================================================================================
 // Block-wide reductions.  Partials are stored per lane in sh.pl/sh.pr (12 slots); after a barrier the first wave
@@ -163,7 +212,7 @@ enum { W_Y = 0, W_Z = 1, W_U = 2, W_E = 3, W_CA = 4, W_CB = 5, W_CY = 6, W_DY = 
 template <int K>
 CSDO_FN void red_put(const Shm& sh, int t, const double (&part)[K]) {
   static_assert(K <= 12, "reduction scratch holds 12 values per lane");
-  CSDO_FOR(k, K, { sh.pl[k * sh.stride + t] = part[k]; });
+  CSDO_FOR(k, K, { sh.red[t * LD_red + k] = part[k]; });
 }
 
 #if defined(CSDO_LANE_MODE_DEVICE)
@@ -185,7 +234,7 @@ CSDO_FN void red_fold(const Shm& sh, int Nt, double (&out)[K]) {
     CSDO_FOR(k, K, {
       double acc = 0.0;
       for (int j = tid; j < Nt; j += 64) {
-        const double v = sh.pl[k * sh.stride + j];
+        const double v = sh.red[j * LD_red + k];
         acc = IS_SUM ? (acc + v) : dmax(acc, v);
       }
       for (int off = 32; off >= 1; off >>= 1) {
@@ -204,7 +253,7 @@ CSDO_FN void red_fold(const Shm& sh, int Nt, double (&out)[K]) {
     for (int l = 0; l < 64; ++l) {
       double acc = 0.0;
       for (int j = l; j < Nt; j += 64) {
-        const double v = sh.pl[k * sh.stride + j];
+        const double v = sh.red[j * LD_red + k];
         acc = IS_SUM ? (acc + v) : dmax(acc, v);
       }
       lane[l] = acc;
@@ -223,75 +272,91 @@ struct BoxD {
   double x_min, y_min, x_max, y_max;
 };
 
-CSDO_FN bool box_valid(const BoxD& b, const double* obs, int n_obs, double dimx, double dimy, double rv) {
+// Obstacles that can ever matter for boxes grown from (xc, yc): a box never extends more than 10.1 m from its seed
+// (101 steps of 0.1 m, corridor.cc:305), so an obstacle whose inflated square cannot reach that extent fails at least
+// one of the four strict inequalities for every box of this seed.  The 0.5 m slack dwarfs any rounding, so skipping
+// those obstacles is exact.  Up to 256 obstacles as four 64-bit masks held in registers.
+struct ObsMask {
+  unsigned long long m[4];
+};
+constexpr int OBS_MASK_CAP = 256;
+
+CSDO_FN ObsMask cull_obstacles(double xc, double yc, const double* obs, int n_obs, double rv) {
+  ObsMask M;
+  M.m[0] = M.m[1] = M.m[2] = M.m[3] = 0ull;
+  const double reach = 10.1 + 0.5;
+  for (int k = 0; k < n_obs && k < OBS_MASK_CAP; ++k) {
+    const double infl = obs[2 * n_obs + k] + rv + reach;
+    const double dx = obs[k] - xc, dy = obs[n_obs + k] - yc;
+    if (dx > -infl && dx < infl && dy > -infl && dy < infl) {
+      const unsigned long long bit = 1ull << (k & 63);
+      if (k < 64) M.m[0] |= bit;
+      else if (k < 128) M.m[1] |= bit;
+      else if (k < 192) M.m[2] |= bit;
+      else M.m[3] |= bit;
+    }
+  }
+  return M;
+}
+
+CSDO_FN bool obstacle_in_box(const BoxD& b, const double* obs, int n_obs, int k, double rv) {
+  const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
+  return (b.x_min - infl) < ox && ox < (b.x_max + infl) && (b.y_min - infl) < oy && oy < (b.y_max + infl);
+}
+
+CSDO_FN int ctz64(unsigned long long v) {
+#if defined(CSDO_LANE_MODE_DEVICE)
+  return __ffsll((long long)v) - 1;
+#else
+  return __builtin_ctzll(v);
+#endif
+}
+
+CSDO_FN bool box_valid(const BoxD& b, const double* obs, int n_obs, double dimx, double dimy, double rv,
+                       const ObsMask& M) {
   // isBoxValid, corridor.cc:252-272: inside [rv, dim-rv]^2 and no obstacle centre strictly inside the box
   // inflated by (r_obs + rv) on every side
   if (b.x_min < rv || b.x_max > dimx - rv || b.y_min < rv || b.y_max > dimy - rv) return false;
-  for (int k = 0; k < n_obs; ++k) {
-    const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
-    if ((b.x_min - infl) < ox && ox < (b.x_max + infl) && (b.y_min - infl) < oy && oy < (b.y_max + infl))
-      return false;
-  }
-  return true;
+  bool hit = false;   // (a `return` inside CSDO_FOR would only leave its lambda)
+  CSDO_FOR(w, 4, {
+    unsigned long long m = M.m[w];
+    while (m && !hit) {
+      const int k = 64 * w + ctz64(m);
+      m &= m - 1;
+      hit = obstacle_in_box(b, obs, n_obs, k, rv);
+    }
+  });
+  for (int k = OBS_MASK_CAP; k < n_obs && !hit; ++k) hit = obstacle_in_box(b, obs, n_obs, k, rv);
+  return !hit;
 }
 
 // generateLocalBox, corridor.cc:278-324: grow by 0.1 in the order +y, -x, -y, +x until blocked or >= 10 m
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
                       BoxD& res) {
   const double ds = 0.1, l_limit = 10.0;
+  const ObsMask M = cull_obstacles(xc, yc, obs, n_obs, rv);
   BoxD box{xc, yc, xc, yc};
-  double len0 = 0, len1 = 0, len2 = 0, len3 = 0;
-  bool on0 = true, on1 = true, on2 = true, on3 = true;
+  double len[4] = {0, 0, 0, 0};
+  bool on[4] = {true, true, true, true};
   int num_expand = 0;
-  while (on0 || on1 || on2 || on3) {
-    if (on0) {
-      BoxD tr = box;
-      tr.y_max += ds;
-      if (box_valid(tr, obs, n_obs, dimx, dimy, rv)) {
-        num_expand++;
-        len0 += ds;
-        box = tr;
-        if (len0 >= l_limit) on0 = false;
-      } else {
-        on0 = false;
+  while (on[0] || on[1] || on[2] || on[3]) {
+    CSDO_FOR(d, 4, {
+      if (on[d]) {
+        BoxD tr = box;
+        if constexpr (d == 0) tr.y_max += ds;
+        if constexpr (d == 1) tr.x_min -= ds;
+        if constexpr (d == 2) tr.y_min -= ds;
+        if constexpr (d == 3) tr.x_max += ds;
+        if (box_valid(tr, obs, n_obs, dimx, dimy, rv, M)) {
+          num_expand++;
+          len[d] += ds;
+          box = tr;
+          if (len[d] >= l_limit) on[d] = false;
+        } else {
+          on[d] = false;
+        }
       }
-    }
-    if (on1) {
-      BoxD tr = box;
-      tr.x_min -= ds;
-      if (box_valid(tr, obs, n_obs, dimx, dimy, rv)) {
-        num_expand++;
-        len1 += ds;
-        box = tr;
-        if (len1 >= l_limit) on1 = false;
-      } else {
-        on1 = false;
-      }
-    }
-    if (on2) {
-      BoxD tr = box;
-      tr.y_min -= ds;
-      if (box_valid(tr, obs, n_obs, dimx, dimy, rv)) {
-        num_expand++;
-        len2 += ds;
-        box = tr;
-        if (len2 >= l_limit) on2 = false;
-      } else {
-        on2 = false;
-      }
-    }
-    if (on3) {
-      BoxD tr = box;
-      tr.x_max += ds;
-      if (box_valid(tr, obs, n_obs, dimx, dimy, rv)) {
-        num_expand++;
-        len3 += ds;
-        box = tr;
-        if (len3 >= l_limit) on3 = false;
-      } else {
-        on3 = false;
-      }
-    }
+    });
   }
   res = box;
   return num_expand > 0;
@@ -335,7 +400,15 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
       y = hy + d * sin(theta);
       if (x > rv && x < dimx - rv && y > rv && y < dimy - rv) {
         grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand);
-        if (box_valid(cand, obs, n_obs, dimx, dimy, rv)) success = true;
+        ObsMask all;
+        all.m[0] = all.m[1] = all.m[2] = all.m[3] = ~0ull;   // isBoxValid over every obstacle (bits >= n_obs masked below)
+        if (n_obs < 256) {
+          CSDO_FOR(w, 4, {
+            const int lo_ = 64 * w;
+            all.m[w] = (n_obs <= lo_) ? 0ull : ((n_obs - lo_ >= 64) ? ~0ull : ((1ull << (n_obs - lo_)) - 1ull));
+          });
+        }
+        if (box_valid(cand, obs, n_obs, dimx, dimy, rv, all)) success = true;
       }
     }
     if (!success) cand = BoxD{x, y, x, y};  // zero-area fallback
@@ -392,10 +465,9 @@ CSDO_FN void spd_inverse6(const double (&A)[21], double (&inv)[21]) {
 }
 
 CSDO_FN void symv6(const double (&S)[21], const double (&v)[6], double (&out)[6]) {
-  CSDO_FOR(r, 6, {
-    double a = 0.0;
-    CSDO_FOR(c, 6, { a = fma(S[sym(r, c)], v[c], a); });
-    out[r] = a;
+  CSDO_FOR(r, 6, { out[r] = 0.0; });
+  CSDO_FOR(c, 6, {  // column sweep: six independent accumulators
+    CSDO_FOR(r, 6, { out[r] = fma(S[sym(r, c)], v[c], out[r]); });
   });
 }
 
@@ -418,14 +490,16 @@ CSDO_FN void rows_times_x(const LaneState& S, const double (&x)[6], const double
   });
 }
 
-CSDO_FN double rho_of(const LaneState& S, int i, double rho) {
+CSDO_FN double rho_of_masks(unsigned eqmask, unsigned loosemask, int i, double rho) {
   const unsigned bit = 1u << i;
-  return (S.loosemask & bit) ? RHO_MIN : ((S.eqmask & bit) ? RHO_EQ_OVER_RHO_INEQ * rho : rho);
+  return (loosemask & bit) ? RHO_MIN : ((eqmask & bit) ? RHO_EQ_OVER_RHO_INEQ * rho : rho);
 }
+CSDO_FN double rho_of(const LaneState& S, int i, double rho) { return rho_of_masks(S.eqmask, S.loosemask, i, rho); }
 
-template <class LaneStore>
-CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, LaneStore&& lanes,
-                           ProgramOut& out);
+// BIG: horizons whose E_r blocks and bounds do not fit in LDS (Nt > 256) read them from the workspace instead.
+template <int ROLE, bool BIG, class RowStore, class SolvStore>
+CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
+                           SolvStore&& lanes_s, ProgramOut& out);
 
 }  // namespace csdo
 

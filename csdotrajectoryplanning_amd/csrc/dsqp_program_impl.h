@@ -4,8 +4,15 @@
 
 namespace csdo {
 
-#define SH(arr, k, t) sh.arr[(k) * sh.stride + (t)]
+// LDS arrays are lane-major: element k of lane t at arr[t * LD + k] (one address register + immediate offsets; the
+// strides 6 and 73 doubles are bank-conflict free for the b64/b128 reads of neighbouring and of 2h-strided lanes)
+#define SH(arr, k, t) sh.arr[(t) * LD_##arr + (k)]
+// factor-time exchange lives in global memory, coalesced [k][stride]
+#define SX(k, t) sh.facX[(k) * sh.stride + (t)]
+// E_r of node t: LDS copy, or the workspace copy for long horizons
+#define ER(k, t) (BIG ? SH(facE, 36 + (k), t) : SH(er, k, t))
 #define CD(slot, t) sh.cold[(slot) * sh.stride + (t)]
+#define WS(slot, t) sh.cold[(slot) * sh.stride + (t)]
 
 // ---------------------------------------------------------------------------------------------------------
 // Assembly of the home rows of timestep t at the linearisation point S.sol0 (unscaled values).
@@ -100,9 +107,9 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 }
 
 // =========================================================================================================
-template <class LaneStore>
-CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, LaneStore&& lanes,
-                           ProgramOut& out) {
+template <int ROLE, bool BIG, class RowStore, class SolvStore>
+CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
+                           SolvStore&& lanes_s, ProgramOut& out) {
   const AgentDesc ad = B.agents[agent];
   const WorldDesc wd = B.worlds[ad.world];
   const SolverParams& P = B.prm;
@@ -111,13 +118,19 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   const PlaneDev* planes = B.planes + ad.plane_off;
   const int32_t* tstart = B.tstart + ad.tstart_off;
   double* rows = B.rows_ws + ad.rows_off * ROWS_WS_STRIDE;
+  const int64_t rcap = (int64_t)4 * ad.n_planes;
   const int n_obs = wd.n_obs;
   const double dimx = wd.dimx, dimy = wd.dimy, rv = P.rv;
   const bool has_inter = ad.n_planes > 0;
   const double sigma = P.sigma, alpha = P.alpha;
   const int n_vars = 6 * Nt - 2;
+#if defined(CSDO_PROFILE_PHASES)
+  long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long prof_last = (long long)__builtin_amdgcn_s_memtime();
+  int prof_cur = 0;
+#endif
 
-#define ROW(r, f) rows[(int64_t)(r) * ROWS_WS_STRIDE + (f)]
+#define ROW(r, f) rows[(int64_t)(f) * rcap + (r)]
 
   // ---------------------------------------------------------------- phase 0: stage obstacles, load the guess
   CSDO_LANES(t) {
@@ -142,19 +155,32 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   }
   CSDO_SYNC();
 
+  CSDO_PHASE(1);
   // ---------------------------------------------------------------- initial corridors (calcCorridors :164-248)
   // State's disc centres are float members (motion_planning.h:115-118,229-230): round through float here.
-  CSDO_LANES(t) {
+  CSDO_SLANES(t) {  // rear disc on the solver lane
     const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
-    const double cy = cos(pyaw), sy = sin(pyaw);
-    const double xf = (double)(float)(px + P.f2x * cy), xr = (double)(float)(px + P.r2x * cy);
-    const double yf = (double)(float)(py + P.f2x * sy), yr = (double)(float)(py + P.r2x * sy);
-    BoxD bf, br;
-    const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+    const double xr = (double)(float)(px + P.r2x * cos(pyaw)), yr = (double)(float)(py + P.r2x * sin(pyaw));
+    BoxD br;
     const int sr = make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br);
-    CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min; CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
-    CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max; CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
-    const double part[1] = {((sf >> 1) > 0 || (sr >> 1) > 0) ? 1.0 : 0.0};
+    CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
+    CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
+    SH(carry2, 5, t) = ((sr >> 1) > 0) ? 1.0 : 0.0;
+  }
+  double my_flag = 0.0;
+  CSDO_LANES(t) {   // front disc on the row lane
+    const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
+    const double xf = (double)(float)(px + P.f2x * cos(pyaw)), yf = (double)(float)(py + P.f2x * sin(pyaw));
+    BoxD bf;
+    const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+    CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
+    CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
+    SH(carry2, 4, t) = ((sf >> 1) > 0) ? 1.0 : 0.0;
+  }
+  (void)my_flag;
+  CSDO_SYNC();
+  CSDO_LANES(t) {
+    const double part[1] = {dmax(SH(carry2, 4, t), SH(carry2, 5, t))};
     red_put<1>(sh, t, part);
   }
   {
@@ -168,6 +194,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   int it = 0, status = 1, admm_total = 0;
 
   while (delta > th && it < P.max_iter) {
+  CSDO_PHASE(2);
     // ============================================================== assemble the QP (unscaled)
     CSDO_MARK("assemble");
     CSDO_LANES(t) {
@@ -183,15 +210,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           const double Dx = (r < 2) ? dfx : drx, Dy = (r < 2) ? dfy : dry;
           const double Ex = (r < 2) ? exf : exr, Ey = (r < 2) ? eyf : eyr;
           const int rr = 4 * k + r;
-          ROW(rr, W_CA) = a;
-          ROW(rr, W_CB) = bb;
-          ROW(rr, W_CY) = a * Dx + bb * Dy;
-          ROW(rr, W_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
-          ROW(rr, W_E) = 1.0;
+          ROW(rr, R_CA) = a;
+          ROW(rr, R_CB) = bb;
+          ROW(rr, R_CY) = a * Dx + bb * Dy;
+          ROW(rr, R_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
+          ROW(rr, R_E) = 1.0;
         });
       }
     }
 
+  CSDO_PHASE(3);
     // ============================================================== Ruiz equilibration (scaling.c scale_data)
     CSDO_MARK("ruiz");
     double cscale = 1.0;
@@ -228,20 +256,20 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           Et[i] = 1.0 / sqrt(limit_scaling(rn));
         });
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          cn_[0] = dmax(cn_[0], fabs(ROW(r, W_CA)));
-          cn_[1] = dmax(cn_[1], fabs(ROW(r, W_CB)));
-          cn_[2] = dmax(cn_[2], fabs(ROW(r, W_CY)));
+          cn_[0] = dmax(cn_[0], fabs(ROW(r, R_CA)));
+          cn_[1] = dmax(cn_[1], fabs(ROW(r, R_CB)));
+          cn_[2] = dmax(cn_[2], fabs(ROW(r, R_CY)));
         }
         CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_scaling(cn_[j])) : 1.0; });
         // inter rows only touch own columns: scale them now
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double a = ROW(r, W_CA), bb = ROW(r, W_CB), cy = ROW(r, W_CY);
+          const double a = ROW(r, R_CA), bb = ROW(r, R_CB), cy = ROW(r, R_CY);
           const double rn = dmax(dmax(fabs(a), fabs(bb)), fabs(cy));
           const double et = 1.0 / sqrt(limit_scaling(rn));
-          ROW(r, W_CA) = (a * et) * Dt[0];
-          ROW(r, W_CB) = (bb * et) * Dt[1];
-          ROW(r, W_CY) = (cy * et) * Dt[2];
-          ROW(r, W_E) = ROW(r, W_E) * et;
+          ROW(r, R_CA) = (a * et) * Dt[0];
+          ROW(r, R_CB) = (bb * et) * Dt[1];
+          ROW(r, R_CY) = (cy * et) * Dt[2];
+          ROW(r, R_E) = ROW(r, R_E) * et;
         }
         CSDO_FOR(k, 5, { SH(carry2, k, t) = Dt[k]; });
       }
@@ -288,6 +316,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     }
     const double cinv = 1.0 / cscale;
 
+  CSDO_PHASE(4);
     // ============================================================== scaled bounds, row classes, warm start
     CSDO_MARK("warmstart");
     CSDO_LANES(t) {
@@ -304,7 +333,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       });
       S.eqmask = eq;
       S.loosemask = loose;
-      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) ROW(r, W_U) = ROW(r, W_E) * ROW(r, W_U);
+      WS(W_ACT, t) = (double)S.act;
+      WS(W_EQ, t) = (double)eq;
+      WS(W_LOOSE, t) = (double)loose;
+      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) ROW(r, R_U) = ROW(r, R_E) * ROW(r, R_U);
       // osqp_warm_start_x: x <- Dinv x0
       CSDO_FOR(j, 6, { S.x[j] = (1.0 / CD(C_D + j, t)) * CD(C_SOL0 + j, t); });
       CSDO_FOR(k, 4, { SH(carry2, k, t) = S.x[k]; });
@@ -322,48 +354,76 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CD(C_DY + i, t) = 0.0;
       });
       for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-        ROW(r, W_Z) = (ROW(r, W_CA) * S.x[0] + ROW(r, W_CB) * S.x[1]) + ROW(r, W_CY) * S.x[2];
-        ROW(r, W_Y) = 0.0;
-        ROW(r, W_DY) = 0.0;
+        ROW(r, R_Z) = (ROW(r, R_CA) * S.x[0] + ROW(r, R_CB) * S.x[1]) + ROW(r, R_CY) * S.x[2];
+        ROW(r, R_Y) = 0.0;
+        ROW(r, R_DY) = 0.0;
       }
+      // the set-up stage worked in registers; publish the master copy for the cold phases and for load_hot
+      CSDO_FOR(i, NROW, {
+        CSDO_FOR(s, 3, {
+          if constexpr (row_col(i, s) >= 0) WS(W_C + 3 * i + s, t) = S.c[i][s];
+        });
+        WS(W_LO + i, t) = S.lo[i];
+        WS(W_HI + i, t) = S.hi[i];
+        WS(W_Yv + i, t) = S.y[i];
+        WS(W_Zv + i, t) = S.z[i];
+      });
+      CSDO_FOR(i, 4, { WS(W_CN + i, t) = S.cn[i]; });
+      CSDO_FOR(j, 6, { WS(W_X + j, t) = S.x[j]; });
+      WS(W_P + 0, t) = S.Pvv;
+      WS(W_P + 1, t) = S.Pww;
+      WS(W_P + 2, t) = S.Pvn;
     }
 
     double rho = osqp_min(osqp_max(P.rho0, RHO_MIN), RHO_MAX);
 
     // ============================================================== BCR factorisation of H = P + sigma I + A' R A
+    // Runs on the solver lanes from the workspace copy of the scaled QP.
     auto factor = [&](const double rho_now) __attribute__((always_inline)) {
       CSDO_MARK("factor_begin");
-      const double rho_eq = RHO_EQ_OVER_RHO_INEQ * rho_now;
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? rho_of(S, k, rho_now) * S.cn[k] * S.cn[k] : 0.0; });
+      CSDO_PHASE(5);
+      CSDO_SYNC();  // the row lanes' workspace writes (set-up stage / save) must be visible to the solver lanes
+      CSDO_SLANES(t) {
+        const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
+        CSDO_FOR(k, 4, {
+          const double cnk = WS(W_CN + k, t);
+          SH(carry, k, t) = (act & (1u << k)) ? rho_of_masks(eqm, lom, k, rho_now) * cnk * cnk : 0.0;
+        });
       }
       CSDO_SYNC();
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        double* A = S.fa;
-        double* R = S.fr;
+      CSDO_SLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
+        const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
+        const int ncols = (t < Nm) ? 6 : 4;
+        double* A = V.fa;
+        double* R = V.fr;
         CSDO_FOR(k, 21, { A[k] = 0.0; });
         CSDO_FOR(k, 36, { R[k] = 0.0; });
-        CSDO_FOR(j, 6, { A[sym(j, j)] = (j < S.ncols) ? sigma : 1.0; });
-        A[sym(4, 4)] += S.Pvv;
-        A[sym(5, 5)] += S.Pww;
+        CSDO_FOR(j, 6, { A[sym(j, j)] = (j < ncols) ? sigma : 1.0; });
+        A[sym(4, 4)] += WS(W_P + 0, t);
+        A[sym(5, 5)] += WS(W_P + 1, t);
         if (t > 0) CSDO_FOR(k, 4, { A[sym(k, k)] += SH(carry, k, t - 1); });
         CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
-            const double rh = rho_of(S, i, rho_now);
+          if (act & (1u << i)) {
+            const double rh = rho_of_masks(eqm, lom, i, rho_now);
+            double ci[3] = {0, 0, 0};
+            CSDO_FOR(s1, 3, {
+              if constexpr (row_col(i, s1) >= 0) ci[s1] = WS(W_C + 3 * i + s1, t);
+            });
+            double cni = 0.0;
+            if constexpr (i < 4) cni = WS(W_CN + i, t);
             CSDO_FOR(s1, 3, {
               if constexpr (row_col(i, s1) >= 0) {
-                const double rc = rh * S.c[i][s1];
-                CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, S.c[i][s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
-                if constexpr (i < 4) R[i * 6 + row_col(i, s1)] = fma(rc, S.cn[i], R[i * 6 + row_col(i, s1)]);
+                const double rc = rh * ci[s1];
+                CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, ci[s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
+                if constexpr (i < 4) R[i * 6 + row_col(i, s1)] = fma(rc, cni, R[i * 6 + row_col(i, s1)]);
               }
             });
           }
         });
-        R[4 * 6 + 4] += S.Pvn;
+        R[4 * 6 + 4] += WS(W_P + 2, t);
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double a = ROW(r, W_CA), bb = ROW(r, W_CB), cy = ROW(r, W_CY);
+          const double a = ROW(r, R_CA), bb = ROW(r, R_CB), cy = ROW(r, R_CY);
           // inter rows have l = -inf and finite u: never loose, never equality (u - l = inf)
           A[sym(0, 0)] = fma(rho_now * a, a, A[sym(0, 0)]);
           A[sym(1, 0)] = fma(rho_now * bb, a, A[sym(1, 0)]);
@@ -373,19 +433,18 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
         }
       }
-      (void)rho_eq;
       for (int h = 1; h < Nt; h <<= 1) {
         const int m2 = 2 * h - 1;
-        CSDO_LANES(t) {  // every active node publishes its coupling to the right neighbour
-          LaneState& S = CSDO_LS(t);
+        CSDO_SLANES(t) {  // every active node publishes its coupling to the right neighbour (= its E_r once eliminated)
+          SolvRegs& V = CSDO_SS(t);
           if ((t & (h - 1)) == 0) {
             const bool has_r = (t + h) < Nt;
-            CSDO_FOR(k, 36, { SH(facE, 36 + k, t) = has_r ? S.fr[k] : 0.0; });
+            CSDO_FOR(k, 36, { SH(facE, 36 + k, t) = has_r ? V.fr[k] : 0.0; });
           }
         }
         CSDO_SYNC();
-        CSDO_LANES(t) {  // eliminated nodes
-          LaneState& S = CSDO_LS(t);
+        CSDO_SLANES(t) {  // eliminated nodes
+          SolvRegs& V = CSDO_SS(t);
           if ((t & m2) == h) {
             double Rl[36];
             CSDO_FOR(k, 36, {
@@ -393,14 +452,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               SH(facE, k, t) = Rl[k];
             });
             double Ain[21];
-            CSDO_FOR(k, 21, { Ain[k] = S.fa[k]; });
-            spd_inverse6(Ain, S.sinv);
+            CSDO_FOR(k, 21, { Ain[k] = V.fa[k]; });
+            spd_inverse6(Ain, V.sinv);
+            CSDO_FOR(k, 21, { WS(W_SINV + k, t) = V.sinv[k]; });
             // T = Sinv * Rl   (rows: own vars, cols: left node's vars)
             double T[36];
             CSDO_FOR(r, 6, {
               CSDO_FOR(c, 6, {
                 double a = 0.0;
-                CSDO_FOR(k, 6, { a = fma(S.sinv[sym(r, k)], Rl[k * 6 + c], a); });
+                CSDO_FOR(k, 6, { a = fma(V.sinv[sym(r, k)], Rl[k * 6 + c], a); });
                 T[r * 6 + c] = a;
               });
             });
@@ -409,25 +469,25 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               CSDO_FOR(b_, a_ + 1, {
                 double a = 0.0;
                 CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], T[k * 6 + b_], a); });
-                SH(facX, sym(a_, b_), t) = a;
+                SX(sym(a_, b_), t) = a;
               });
             });
             if ((t + h) < Nt) {
-              const double* Rr = S.fr;
+              const double* Rr = V.fr;
               // V = Sinv * Rr'  (rows: own vars, cols: right node's vars)
-              double V[36];
+              double Vm[36];
               CSDO_FOR(r, 6, {
                 CSDO_FOR(c, 6, {
                   double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(S.sinv[sym(r, k)], Rr[c * 6 + k], a); });
-                  V[r * 6 + c] = a;
+                  CSDO_FOR(k, 6, { a = fma(V.sinv[sym(r, k)], Rr[c * 6 + k], a); });
+                  Vm[r * 6 + c] = a;
                 });
               });
               CSDO_FOR(a_, 6, {
                 CSDO_FOR(b_, a_ + 1, {
                   double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], V[k * 6 + b_], a); });
-                  SH(facX, 21 + sym(a_, b_), t) = a;
+                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], Vm[k * 6 + b_], a); });
+                  SX(21 + sym(a_, b_), t) = a;
                 });
               });
               // new coupling (right node <- left node) = -Rr * T
@@ -435,113 +495,125 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
                 CSDO_FOR(b_, 6, {
                   double a = 0.0;
                   CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], T[k * 6 + b_], a); });
-                  SH(facX, 42 + a_ * 6 + b_, t) = -a;
+                  SX(42 + a_ * 6 + b_, t) = -a;
                 });
               });
             }
           }
         }
         CSDO_SYNC();
-        CSDO_LANES(t) {  // remaining nodes absorb the Schur complements
-          LaneState& S = CSDO_LS(t);
+        CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements
+          SolvRegs& V = CSDO_SS(t);
           if ((t & m2) == 0) {
-            if (t >= h) CSDO_FOR(k, 21, { S.fa[k] -= SH(facX, 21 + k, t - h); });
+            if (t >= h) CSDO_FOR(k, 21, { V.fa[k] -= SX(21 + k, t - h); });
             if ((t + h) < Nt) {
-              CSDO_FOR(k, 21, { S.fa[k] -= SH(facX, k, t + h); });
+              CSDO_FOR(k, 21, { V.fa[k] -= SX(k, t + h); });
               const bool has_rr = (t + 2 * h) < Nt;
-              CSDO_FOR(k, 36, { S.fr[k] = has_rr ? SH(facX, 42 + k, t + h) : 0.0; });
+              CSDO_FOR(k, 36, { V.fr[k] = has_rr ? SX(42 + k, t + h) : 0.0; });
             }
           }
         }
       }
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
+      CSDO_SLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
         if (t == 0) {
           double Ain[21];
-          CSDO_FOR(k, 21, { Ain[k] = S.fa[k]; });
-          spd_inverse6(Ain, S.sinv);
+          CSDO_FOR(k, 21, { Ain[k] = V.fa[k]; });
+          spd_inverse6(Ain, V.sinv);
+          CSDO_FOR(k, 21, { WS(W_SINV + k, t) = V.sinv[k]; });
+          CSDO_FOR(k, 72, { SH(facE, k, 0) = 0.0; });
         }
       }
       CSDO_SYNC();
     };
 
-    // ============================================================== BCR solve: S.b (rhs) -> S.b (solution), also in sh.vec
+    // ============================================================== BCR solve on the solver lanes.
+    // In: rhs of lane t in sh.vec[t] (written by the row lane).  Out: x_tilde in V.b and sh.vec[t].
+    // Coupling blocks and pivot inverses come from registers: the only LDS traffic is the 6-vectors.
     auto solve = [&]() __attribute__((always_inline)) {
       CSDO_MARK("solve_begin");
+      CSDO_PHASE(7);
       int htop = 1;
       for (int h = 1; h < Nt; h <<= 1) {
         const int m2 = 2 * h - 1;
         htop = h;
-        CSDO_LANES(t) {
-          LaneState& S = CSDO_LS(t);
+        CSDO_SLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
+          if (h == 1) CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
           if (h > 1 && (t & (h - 1)) == 0) {  // absorb the partials of the previous level
             const int hp = h >> 1;
-            if (t >= hp) CSDO_FOR(k, 6, { S.b[k] -= SH(pr, k, t - hp); });
-            if ((t + hp) < Nt) CSDO_FOR(k, 6, { S.b[k] -= SH(pl, k, t + hp); });
+            if (t >= hp) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - hp); });
+            if ((t + hp) < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + hp); });
           }
           if ((t & m2) == h) {
             double w[6];
-            symv6(S.sinv, S.b, w);
-            CSDO_FOR(k, 6, { S.b[k] = w[k]; });
-            CSDO_FOR(bcol, 6, {  // pl = E_l' w
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(SH(facE, k * 6 + bcol, t), w[k], a); });
-              SH(pl, bcol, t) = a;
+            symv6(V.sinv, V.b, w);
+            CSDO_FOR(k, 6, { V.b[k] = w[k]; });
+            double pl6[6] = {0, 0, 0, 0, 0, 0};
+            CSDO_FOR(k, 6, {  // pl = E_l' w, six independent accumulators
+              CSDO_FOR(bcol, 6, { pl6[bcol] = fma(V.el[k * 6 + bcol], w[k], pl6[bcol]); });
             });
+            CSDO_FOR(bcol, 6, { SH(pl, bcol, t) = pl6[bcol]; });
             if ((t + h) < Nt) {
-              CSDO_FOR(arow, 6, {  // pr = E_r w
-                double a = 0.0;
-                CSDO_FOR(k, 6, { a = fma(SH(facE, 36 + arow * 6 + k, t), w[k], a); });
-                SH(pr, arow, t) = a;
+              double er_[36];
+              CSDO_FOR(k, 36, { er_[k] = ER(k, t); });
+              double pr6[6] = {0, 0, 0, 0, 0, 0};
+              CSDO_FOR(k, 6, {  // pr = E_r w
+                CSDO_FOR(arow, 6, { pr6[arow] = fma(er_[arow * 6 + k], w[k], pr6[arow]); });
               });
+              CSDO_FOR(arow, 6, { SH(pr, arow, t) = pr6[arow]; });
             }
           }
         }
+        CSDO_PHASE(13);
         CSDO_SYNC();
+        CSDO_PHASE(7);
       }
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
+      CSDO_SLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
         if (t == 0) {
-          if (htop < Nt) CSDO_FOR(k, 6, { S.b[k] -= SH(pl, k, htop); });
+          if (Nt == 1) CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
+          if (htop < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, htop); });
           double w[6];
-          symv6(S.sinv, S.b, w);
+          symv6(V.sinv, V.b, w);
           CSDO_FOR(k, 6, {
-            S.b[k] = w[k];
+            V.b[k] = w[k];
             SH(vec, k, 0) = w[k];
           });
         }
       }
       CSDO_SYNC();
+      CSDO_PHASE(8);
       for (int h = htop; h >= 1; h >>= 1) {
         const int m2 = 2 * h - 1;
-        CSDO_LANES(t) {
-          LaneState& S = CSDO_LS(t);
+        CSDO_SLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
           if ((t & m2) == h) {
-            double xl[6], tmp[6];
+            double xl[6], tmp[6] = {0, 0, 0, 0, 0, 0};
             CSDO_FOR(k, 6, { xl[k] = SH(vec, k, t - h); });
-            CSDO_FOR(r, 6, {
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(SH(facE, r * 6 + k, t), xl[k], a); });
-              tmp[r] = a;
+            CSDO_FOR(k, 6, {
+              CSDO_FOR(r, 6, { tmp[r] = fma(V.el[r * 6 + k], xl[k], tmp[r]); });
             });
             if ((t + h) < Nt) {
               double xr[6];
               CSDO_FOR(k, 6, { xr[k] = SH(vec, k, t + h); });
-              CSDO_FOR(r, 6, {
-                double a = tmp[r];
-                CSDO_FOR(k, 6, { a = fma(SH(facE, 36 + k * 6 + r, t), xr[k], a); });
-                tmp[r] = a;
+              double er_[36];
+              CSDO_FOR(k, 36, { er_[k] = ER(k, t); });
+              CSDO_FOR(k, 6, {
+                CSDO_FOR(r, 6, { tmp[r] = fma(er_[k * 6 + r], xr[k], tmp[r]); });
               });
             }
             double corr[6];
-            symv6(S.sinv, tmp, corr);
+            symv6(V.sinv, tmp, corr);
             CSDO_FOR(k, 6, {
-              S.b[k] = S.b[k] - corr[k];
-              SH(vec, k, t) = S.b[k];
+              V.b[k] = V.b[k] - corr[k];
+              SH(vec, k, t) = V.b[k];
             });
           }
         }
+        CSDO_PHASE(14);
         CSDO_SYNC();
+        CSDO_PHASE(8);
       }
     };
 
@@ -556,7 +628,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_FOR(k, 12, { nrm[k] = 0.0; });
     bool info_valid = false;
 
-    // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective
+    // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective; works from the workspace
     auto primal_infeasible = [&](const double eps_pinf) __attribute__((always_inline)) -> bool {
       CSDO_MARK("pinf_begin");
       CSDO_LANES(t) {
@@ -564,21 +636,22 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         double nmax = 0.0;
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
-            double dyi = CD(C_DY + i, t);
-            if (S.hi[i] > OSQP_INFTY * MIN_SCALING) {
-              if (S.lo[i] < -OSQP_INFTY * MIN_SCALING) dyi = 0.0;
+            double dyi = WS(C_DY + i, t);
+            const double hi_i = WS(W_HI + i, t), lo_i = WS(W_LO + i, t);
+            if (hi_i > OSQP_INFTY * MIN_SCALING) {
+              if (lo_i < -OSQP_INFTY * MIN_SCALING) dyi = 0.0;
               else dyi = osqp_min(dyi, 0.0);
-            } else if (S.lo[i] < -OSQP_INFTY * MIN_SCALING) {
+            } else if (lo_i < -OSQP_INFTY * MIN_SCALING) {
               dyi = osqp_max(dyi, 0.0);
             }
-            CD(C_DY + i, t) = dyi;
-            nmax = dmax(nmax, fabs(CD(C_E + i, t) * dyi));
+            WS(C_DY + i, t) = dyi;
+            nmax = dmax(nmax, fabs(WS(C_E + i, t) * dyi));
           }
         });
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {  // l = -inf, u finite
-          const double d = osqp_max(ROW(r, W_DY), 0.0);
-          ROW(r, W_DY) = d;
-          nmax = dmax(nmax, fabs(ROW(r, W_E) * d));
+          const double d = osqp_max(ROW(r, R_DY), 0.0);
+          ROW(r, R_DY) = d;
+          nmax = dmax(nmax, fabs(ROW(r, R_E) * d));
         }
         const double part[1] = {nmax};
         red_put<1>(sh, t, part);
@@ -592,15 +665,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         double acc = 0.0;
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
-            const double dyi = CD(C_DY + i, t);
-            acc += S.hi[i] * osqp_max(dyi, 0.0) + S.lo[i] * osqp_min(dyi, 0.0);
+            const double dyi = WS(C_DY + i, t);
+            acc += WS(W_HI + i, t) * osqp_max(dyi, 0.0) + WS(W_LO + i, t) * osqp_min(dyi, 0.0);
           }
         });
         // reference quirk: l = -infinity (a true IEEE inf, dsqp_solver.cc:1121-1123) times min(dy,0) = 0 is NaN, so
         // the certificate test is false for every agent that has inter-vehicle rows; IEEE arithmetic reproduces it
         const double ninf = -INFINITY;
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r)
-          acc += ROW(r, W_U) * osqp_max(ROW(r, W_DY), 0.0) + ninf * osqp_min(ROW(r, W_DY), 0.0);
+          acc += ROW(r, R_U) * osqp_max(ROW(r, R_DY), 0.0) + ninf * osqp_min(ROW(r, R_DY), 0.0);
         const double part[1] = {acc};
         red_put<1>(sh, t, part);
       }
@@ -610,7 +683,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // || Dinv A' dy ||
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * CD(C_DY + k, t) : 0.0; });
+        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? WS(W_CN + k, t) * WS(C_DY + k, t) : 0.0; });
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
@@ -619,21 +692,21 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         if (t > 0) CSDO_FOR(k, 4, { v[k] = SH(carry, k, t - 1); });
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
-            const double dyi = CD(C_DY + i, t);
+            const double dyi = WS(C_DY + i, t);
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(S.c[i][s], dyi, v[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(WS(W_C + 3 * i + s, t), dyi, v[row_col(i, s)]);
             });
           }
         });
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double d = ROW(r, W_DY);
-          v[0] = fma(ROW(r, W_CA), d, v[0]);
-          v[1] = fma(ROW(r, W_CB), d, v[1]);
-          v[2] = fma(ROW(r, W_CY), d, v[2]);
+          const double d = ROW(r, R_DY);
+          v[0] = fma(ROW(r, R_CA), d, v[0]);
+          v[1] = fma(ROW(r, R_CB), d, v[1]);
+          v[2] = fma(ROW(r, R_CY), d, v[2]);
         }
         double nmax = 0.0;
         CSDO_FOR(j, 6, {
-          if (j < S.ncols) nmax = dmax(nmax, fabs((1.0 / CD(C_D + j, t)) * v[j]));
+          if (j < S.ncols) nmax = dmax(nmax, fabs((1.0 / WS(C_D + j, t)) * v[j]));
         });
         const double part[1] = {nmax};
         red_put<1>(sh, t, part);
@@ -676,15 +749,19 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       return false;
     };
 
-    // update_info (auxil.c): residuals of the current (x, z, y), unscaled for the test and scaled for adapt_rho
+    // update_info (auxil.c): residuals of the current (x, z, y) read from the workspace, unscaled for the
+    // termination test and scaled for adapt_rho
     auto update_info = [&]() __attribute__((always_inline)) {
       CSDO_MARK("info_begin");
+      CSDO_PHASE(10);
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 5, { SH(carry2, k, t) = S.x[k]; });        // to t-1: x_{t+1} cols 0..3 and v_{t+1}
-        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * S.y[k] : 0.0; });  // to t+1: A'y share
-        SH(carry, 4, t) = S.x[4];
-        SH(carry, 5, t) = S.Pvn;
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = WS(W_X + k, t); });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
+        CSDO_FOR(k, 4, {                                           // to t+1: A'y share of the kinematic rows
+          SH(carry, k, t) = (S.act & (1u << k)) ? WS(W_CN + k, t) * WS(W_Yv + k, t) : 0.0;
+        });
+        SH(carry, 4, t) = WS(W_X + 4, t);
+        SH(carry, 5, t) = WS(W_P + 2, t);
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
@@ -701,28 +778,38 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           vp = SH(carry, 4, t - 1);
           pvn_left = SH(carry, 5, t - 1);
         }
-        double Ax[NROW];
-        rows_times_x(S, S.x, xn, Ax);
+        double xx[6];
+        CSDO_FOR(j, 6, { xx[j] = WS(W_X + j, t); });
         double p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
-            const double einv = 1.0 / CD(C_E + i, t);
-            const double res = Ax[i] - S.z[i];
-            p[0] = dmax(p[0], fabs(einv * res));
-            p[1] = dmax(p[1], fabs(einv * S.z[i]));
-            p[2] = dmax(p[2], fabs(einv * Ax[i]));
-            p[3] = dmax(p[3], fabs(res));
-            p[4] = dmax(p[4], fabs(S.z[i]));
-            p[5] = dmax(p[5], fabs(Ax[i]));
+            double ax = 0.0;
+            double ci[3] = {0, 0, 0};
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(S.c[i][s], S.y[i], Aty[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) {
+                ci[s] = WS(W_C + 3 * i + s, t);
+                ax = fma(ci[s], xx[row_col(i, s)], ax);
+              }
+            });
+            if constexpr (i < 4) ax = fma(WS(W_CN + i, t), xn[i], ax);
+            const double zi = WS(W_Zv + i, t), yi = WS(W_Yv + i, t);
+            const double einv = 1.0 / WS(C_E + i, t);
+            const double res = ax - zi;
+            p[0] = dmax(p[0], fabs(einv * res));
+            p[1] = dmax(p[1], fabs(einv * zi));
+            p[2] = dmax(p[2], fabs(einv * ax));
+            p[3] = dmax(p[3], fabs(res));
+            p[4] = dmax(p[4], fabs(zi));
+            p[5] = dmax(p[5], fabs(ax));
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(ci[s], yi, Aty[row_col(i, s)]);
             });
           }
         });
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double ca = ROW(r, W_CA), cb = ROW(r, W_CB), cy = ROW(r, W_CY);
-          const double ax = (ca * S.x[0] + cb * S.x[1]) + cy * S.x[2];
-          const double zz = ROW(r, W_Z), yy = ROW(r, W_Y), einv = 1.0 / ROW(r, W_E);
+          const double ca = ROW(r, R_CA), cb = ROW(r, R_CB), cy = ROW(r, R_CY);
+          const double ax = (ca * xx[0] + cb * xx[1]) + cy * xx[2];
+          const double zz = ROW(r, R_Z), yy = ROW(r, R_Y), einv = 1.0 / ROW(r, R_E);
           const double res = ax - zz;
           p[0] = dmax(p[0], fabs(einv * res));
           p[1] = dmax(p[1], fabs(einv * zz));
@@ -736,12 +823,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         double Px[6] = {0, 0, 0, 0, 0, 0};
         if (t < Nm) {
-          Px[4] = (S.Pvv * S.x[4] + S.Pvn * vn) + pvn_left * vp;
-          Px[5] = S.Pww * S.x[5];
+          Px[4] = (WS(W_P + 0, t) * xx[4] + WS(W_P + 2, t) * vn) + pvn_left * vp;
+          Px[5] = WS(W_P + 1, t) * xx[5];
         }
         CSDO_FOR(j, 6, {
           if (j < S.ncols) {
-            const double dinv = 1.0 / CD(C_D + j, t);
+            const double dinv = 1.0 / WS(C_D + j, t);
             const double dr = (0.0 + Px[j]) + Aty[j];
             p[6] = dmax(p[6], fabs(dinv * dr));
             p[7] = dmax(p[7], fabs(dinv * Aty[j]));
@@ -757,84 +844,194 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       info_valid = true;
     };
 
-    bool can_check = false;
-    for (iter = 1; iter <= max_it; ++iter) {
-      // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
-    CSDO_MARK("rhs");
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 4, {
-          SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_of(S, k, rho), S.z[k], -S.y[k]) : 0.0;
+    // ---- the ADMM loop runs in blocks that end where osqp_solve would look at the iterate (termination check,
+    // rho adaptation, iteration cap).  Inside a block only register state and the LDS 6-vectors are touched, plus the
+    // inter-vehicle rows of the solver lanes.
+    // Inter-vehicle rows of timestep t belong to solver lane t: `inter_pass<UPDATE>` walks the planes at t (the 4 rows
+    // of a plane are loaded together), optionally applies the z / y update with x_tilde = V.b, and leaves
+    // A'(rho z - y) restricted to those rows in sh.carry2[t][0..2] for the row lane's next rhs.
+    auto inter_pass = [&](auto update_c, const int t, const double (&xt)[6], const double rho_now,
+                          const bool keep_dy) __attribute__((always_inline)) {
+      constexpr bool UPDATE = decltype(update_c)::value;
+      double ic[3] = {0, 0, 0};
+      const double rinv = 1.0 / rho_now;
+      for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
+        double zz[4], yy[4], ca[4], cb[4], cy[4], uu[4];
+        CSDO_FOR(q, 4, {
+          zz[q] = ROW(4 * k + q, R_Z);
+          yy[q] = ROW(4 * k + q, R_Y);
+          ca[q] = ROW(4 * k + q, R_CA);
+          cb[q] = ROW(4 * k + q, R_CB);
+          cy[q] = ROW(4 * k + q, R_CY);
+          if constexpr (UPDATE) uu[q] = ROW(4 * k + q, R_U);
         });
+        CSDO_FOR(q, 4, {
+          double zq = zz[q], yq = yy[q];
+          if constexpr (UPDATE) {
+            const double ztr = (ca[q] * xt[0] + cb[q] * xt[1]) + cy[q] * xt[2];
+            const double zr = alpha * ztr + (1.0 - alpha) * zq;
+            const double zn = osqp_min(zr + rinv * yq, uu[q]);  // lower bound is -inf
+            const double d = rho_now * (zr - zn);
+            if (keep_dy) ROW(4 * k + q, R_DY) = d;
+            yq = yq + d;
+            zq = zn;
+            ROW(4 * k + q, R_Y) = yq;
+            ROW(4 * k + q, R_Z) = zq;
+          }
+          const double g = fma(rho_now, zq, -yq);
+          ic[0] = fma(ca[q], g, ic[0]);
+          ic[1] = fma(cb[q], g, ic[1]);
+          ic[2] = fma(cy[q], g, ic[2]);
+        });
+      }
+      CSDO_FOR(k, 3, { SH(carry2, k, t) = ic[k]; });
+    };
+
+    bool can_check = false;
+    bool finished = false;
+    iter = 0;
+    while (!finished) {
+      int stop = max_it;
+      if (chk) stop = osqp_min_i(stop, (iter / chk + 1) * chk);
+      if (P.adaptive_rho_interval) stop = osqp_min_i(stop, (iter / P.adaptive_rho_interval + 1) * P.adaptive_rho_interval);
+      CSDO_PHASE(12);
+      CSDO_LANES(t) {  // load the row-lane cache
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(i, NROW, {
+          CSDO_FOR(s, 3, {
+            if constexpr (row_col(i, s) >= 0) S.c[i][s] = WS(W_C + 3 * i + s, t);
+          });
+          // bounds are read once per iteration: LDS, not registers (layout: Shm::lohi)
+          if constexpr (!BIG) {
+            if constexpr (i < 7) SH(lohi, i, t) = WS(W_LO + i, t);
+            if constexpr (i >= 7 && i < 13) {
+              SH(lohi, i, t) = WS(W_LO + i, t);
+              SH(lohi, i + 6, t) = WS(W_HI + i, t);
+            }
+            if constexpr (i >= 13) SH(lohi, i + 6, t) = WS(W_HI + i, t);
+          }
+          S.y[i] = WS(W_Yv + i, t);
+          S.z[i] = WS(W_Zv + i, t);
+        });
+        CSDO_FOR(i, 4, { S.cn[i] = WS(W_CN + i, t); });
+        CSDO_FOR(j, 6, { S.x[j] = WS(W_X + j, t); });
+        S.act = (unsigned)WS(W_ACT, t);
+        S.eqmask = (unsigned)WS(W_EQ, t);
+        S.loosemask = (unsigned)WS(W_LOOSE, t);
+        S.ncols = (t < Nm) ? 6 : 4;
+      }
+      CSDO_SLANES(t) {  // load the solver-lane cache and the inter-row share of the first rhs
+        SolvRegs& V = CSDO_SS(t);
+        CSDO_FOR(k, 21, { V.sinv[k] = WS(W_SINV + k, t); });
+        CSDO_FOR(k, 36, {
+          V.el[k] = SH(facE, k, t);
+          if constexpr (!BIG) SH(er, k, t) = SH(facE, 36 + k, t);
+        });
+        const double none[6] = {0, 0, 0, 0, 0, 0};
+        inter_pass(std::false_type{}, t, none, rho, false);
       }
       CSDO_SYNC();
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        double r6[6];
-        CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
-        if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
-        CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
-            const double g = fma(rho_of(S, i, rho), S.z[i], -S.y[i]);
-            CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) r6[row_col(i, s)] = fma(S.c[i][s], g, r6[row_col(i, s)]);
-            });
-          }
-        });
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double g = fma(rho, ROW(r, W_Z), -ROW(r, W_Y));
-          r6[0] = fma(ROW(r, W_CA), g, r6[0]);
-          r6[1] = fma(ROW(r, W_CB), g, r6[1]);
-          r6[2] = fma(ROW(r, W_CY), g, r6[2]);
+      while (iter < stop) {
+        ++iter;
+        CSDO_PHASE(6);
+        // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
+        CSDO_MARK("rhs");
+        CSDO_LANES(t) {
+          LaneState& S = CSDO_LS(t);
+          CSDO_FOR(k, 4, {
+            SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_of(S, k, rho), S.z[k], -S.y[k]) : 0.0;
+          });
         }
-        CSDO_FOR(j, 6, { S.b[j] = r6[j]; });
+        CSDO_SYNC();
+        CSDO_LANES(t) {
+          LaneState& S = CSDO_LS(t);
+          double r6[6];
+          CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
+          if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
+          CSDO_FOR(i, NROW, {
+            if (S.act & (1u << i)) {
+              const double g = fma(rho_of(S, i, rho), S.z[i], -S.y[i]);
+              CSDO_FOR(s, 3, {
+                if constexpr (row_col(i, s) >= 0) r6[row_col(i, s)] = fma(S.c[i][s], g, r6[row_col(i, s)]);
+              });
+            }
+          });
+          CSDO_FOR(k, 3, { r6[k] += SH(carry2, k, t); });   // inter-vehicle rows, summed by the solver lane
+          CSDO_FOR(j, 6, { SH(vec, j, t) = r6[j]; });
+        }
+        CSDO_SYNC();
+        solve();
+        CSDO_PHASE(9);
+        // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
+        CSDO_MARK("update");
+        const bool keep_dy = (iter == stop);
+        CSDO_SLANES(t) {  // inter-vehicle rows, concurrently with the row lanes below
+          SolvRegs& V = CSDO_SS(t);
+          inter_pass(std::true_type{}, t, V.b, rho, keep_dy);
+        }
+        CSDO_LANES(t) {
+          LaneState& S = CSDO_LS(t);
+          double xt[6], xn[4] = {0, 0, 0, 0};
+          CSDO_FOR(k, 6, { xt[k] = SH(vec, k, t); });
+          if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
+          CSDO_FOR(i, NROW, {
+            if (S.act & (1u << i)) {
+              double zt = 0.0;
+              CSDO_FOR(s, 3, {
+                if constexpr (row_col(i, s) >= 0) zt = fma(S.c[i][s], xt[row_col(i, s)], zt);
+              });
+              if constexpr (i < 4) zt = fma(S.cn[i], xn[i], zt);
+              const double rh = rho_of(S, i, rho);
+              const double rinv = 1.0 / rh;
+              const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
+              double lo_i, hi_i;
+              if constexpr (BIG) {
+                lo_i = WS(W_LO + i, t);
+                hi_i = WS(W_HI + i, t);
+              } else {
+                if constexpr (i < 7) lo_i = hi_i = SH(lohi, i, t);
+                if constexpr (i >= 7 && i < 13) {
+                  lo_i = SH(lohi, i, t);
+                  hi_i = SH(lohi, i + 6, t);
+                }
+                if constexpr (i >= 13) {
+                  hi_i = SH(lohi, i + 6, t);
+                  lo_i = -hi_i;
+                }
+              }
+              const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], lo_i), hi_i);
+              const double d = rh * (zr - zn);
+              if (keep_dy) WS(C_DY + i, t) = d;
+              S.y[i] += d;
+              S.z[i] = zn;
+            }
+          });
+          CSDO_FOR(j, 6, {
+            if (j < S.ncols) S.x[j] = alpha * xt[j] + (1.0 - alpha) * S.x[j];
+          });
+        }
+        CSDO_SYNC();
       }
-      solve();
-      // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
-    CSDO_MARK("update");
-      const bool keep_dy = (chk && (iter % chk == 0)) || iter == max_it;
-      CSDO_LANES(t) {
+      CSDO_PHASE(12);
+      CSDO_LANES(t) {  // write the iterate back: nothing else changes inside a block
         LaneState& S = CSDO_LS(t);
-        double xn[4] = {0, 0, 0, 0};
-        if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
-        double zt[NROW];
-        rows_times_x(S, S.b, xn, zt);
         CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
-            const double rh = rho_of(S, i, rho);
-            const double rinv = 1.0 / rh;
-            const double zr = alpha * zt[i] + (1.0 - alpha) * S.z[i];
-            const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], S.lo[i]), S.hi[i]);
-            const double d = rh * (zr - zn);
-            if (keep_dy) CD(C_DY + i, t) = d;
-            S.y[i] += d;
-            S.z[i] = zn;
-          }
+          WS(W_Yv + i, t) = S.y[i];
+          WS(W_Zv + i, t) = S.z[i];
         });
-        const double rinv = 1.0 / rho;
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double ztr = (ROW(r, W_CA) * S.b[0] + ROW(r, W_CB) * S.b[1]) + ROW(r, W_CY) * S.b[2];
-          const double zp = ROW(r, W_Z), yy = ROW(r, W_Y);
-          const double zr = alpha * ztr + (1.0 - alpha) * zp;
-          const double zn = osqp_min(zr + rinv * yy, ROW(r, W_U));  // lower bound is -inf
-          const double d = rho * (zr - zn);
-          if (keep_dy) ROW(r, W_DY) = d;
-          ROW(r, W_Y) = yy + d;
-          ROW(r, W_Z) = zn;
-        }
-        CSDO_FOR(j, 6, {
-          if (j < S.ncols) S.x[j] = alpha * S.b[j] + (1.0 - alpha) * S.x[j];
-        });
+        CSDO_FOR(j, 6, { WS(W_X + j, t) = S.x[j]; });
       }
       CSDO_SYNC();
 
       can_check = chk && (iter % chk == 0);
       info_valid = false;
-      if (__builtin_expect(can_check, 0)) {
+      if (can_check) {
         update_info();
         if (check_termination(false)) break;
       }
-      if (__builtin_expect(P.adaptive_rho_interval && (iter % P.adaptive_rho_interval == 0) && iter < max_it, 0)) {
+      if (iter >= max_it) {
+        finished = true;
+      } else if (P.adaptive_rho_interval && (iter % P.adaptive_rho_interval == 0)) {
         if (!info_valid) update_info();
         // compute_rho_estimate (auxil.c), scaled residuals
         double pri = nrm[3], dua = nrm[9];
@@ -851,8 +1048,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
       }
     }
-    if (iter > max_it) {
-      iter = max_it;
+    if (finished && qp_status == -10) {
       if (!can_check) {
         update_info();
         check_termination(false);
@@ -864,6 +1060,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     status = qp_status;
     admm_total += iter;
 
+  CSDO_PHASE(11);
     // ============================================================== SQP bookkeeping (calcIndividualSQP :223-253)
     CSDO_MARK("bookkeeping");
     CSDO_LANES(t) {
@@ -873,7 +1070,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_FOR(j, 6, {
         if (j < S.ncols) {
           const double s0 = CD(C_SOL0 + j, t);
-          const double sn = keep_prev ? s0 : CD(C_D + j, t) * S.x[j];
+          const double sn = keep_prev ? s0 : CD(C_D + j, t) * WS(W_X + j, t);
           CD(C_SOL + j, t) = sn;
           const double d = sn - s0;
           acc = fma(d, d, acc);
@@ -948,20 +1145,29 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     }
     if (feasible) break;
 
-    CSDO_LANES(t) {  // solution0 = solution; updateCorridor :818-872 (double-precision disc centres)
-      CSDO_FOR(k, 6, { CD(C_SOL0 + k, t) = CD(C_SOL + k, t); });
+    CSDO_PHASE(1);
+    CSDO_SLANES(t) {  // updateCorridor :818-872 (double-precision disc centres): rear disc on the solver lane
       if (!P.fixed_corridor) {
         const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
-        const double cy = cos(pyaw), sy = sin(pyaw);
-        const double xf = px + P.f2x * cy, xr = px + P.r2x * cy;
-        const double yf = py + P.f2x * sy, yr = py + P.r2x * sy;
-        BoxD bf, br;
-        make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+        const double xr = px + P.r2x * cos(pyaw), yr = py + P.r2x * sin(pyaw);
+        BoxD br;
         make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br);
-        CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min; CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
-        CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max; CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
+        CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
+        CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
       }
     }
+    CSDO_LANES(t) {  // solution0 = solution; front disc on the row lane
+      if (!P.fixed_corridor) {
+        const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
+        const double xf = px + P.f2x * cos(pyaw), yf = py + P.f2x * sin(pyaw);
+        BoxD bf;
+        make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+        CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
+        CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
+      }
+      CSDO_FOR(k, 6, { CD(C_SOL0 + k, t) = CD(C_SOL + k, t); });
+    }
+    CSDO_SYNC();
   }
 
   // ---------------------------------------------------------------- write results
@@ -974,6 +1180,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       co[2 * k + 1] = CD(C_CUB + k, t);
     });
   }
+#if defined(CSDO_PROFILE_PHASES)
+  CSDO_PHASE(0);
+  if (threadIdx.x == 0 && B.prof)
+    for (int k = 0; k < 16; ++k) B.prof[(int64_t)agent * 16 + k] = prof_acc[k];
+#endif
   out.sqp_iters = it;
   out.admm_iters = admm_total;
   out.last_status = status;
@@ -981,6 +1192,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 }
 
 #undef SH
+#undef SX
+#undef ER
 #undef CD
+#undef WS
 
 }  // namespace csdo

@@ -43,22 +43,26 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
   for (int a = 0; a < Na; ++a) {
     const AgentDesc& ad = hb.agents[a];
     const int st = fac_stride(ad.Nt);
-    std::vector<double> lds((size_t)30 * st + 3 * hb.max_obs + 32, 0.0);
+    std::vector<double> lds((size_t)76 * st + 3 * hb.max_obs + 32, 0.0);
     Shm sh{};
     sh.stride = st;
     sh.vec = lds.data();
     sh.pl = sh.vec + 6 * st;
     sh.pr = sh.pl + 6 * st;
-    sh.carry = sh.pr + 6 * st;
-    sh.carry2 = sh.carry + 6 * st;
-    sh.obs = sh.carry2 + 6 * st;
+    sh.carry = sh.pl;     // aliases, see Shm
+    sh.carry2 = sh.pr;
+    sh.lohi = sh.pr + 6 * st;
+    sh.red = sh.lohi;
+    sh.er = sh.lohi + 22 * st;
+    sh.obs = sh.er + 36 * st;
     sh.bcast = sh.obs + 3 * hb.max_obs;
     sh.facE = fac_ws.data() + ad.fac_off;
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;
     sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
-    std::vector<LaneState> lanes(ad.Nt);
+    std::vector<RowRegs> lanes_r(ad.Nt);
+    std::vector<SolvRegs> lanes_s(ad.Nt);
     ProgramOut po{};
-    agent_program(B, a, sh, lanes.data(), po);
+    agent_program<ROLE_BOTH, false>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     sqp[a] = po.sqp_iters;
     admm[a] = po.admm_iters;
     stat[a] = po.last_status;

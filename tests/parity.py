@@ -5,10 +5,18 @@ and status codes.  One documented exception: the corridor boxes grow in 0.1 m st
 (sqp/corridor.cc:284-315), so a 1e-9 difference in a disc centre can flip one growth step; that changes the agent's
 next QP and moves its trajectory by O(1e-3).  An agent whose final boxes differ by a growth step is therefore held to
 the looser CORRIDOR_FLIP_TOL and must still have the same iteration counts/status.
+
+A second, milder effect: the QP objective only prices (v_{k+1}-v_k)^2 and w^2 (P is singular on 4Nt of 6Nt-2 variables,
+sqp/dsqp_solver.cc:163-197) and ADMM stops at eps = 1e-3, so the returned point of a QP is a sensitive function of its
+data; the oracle factors the full KKT matrix (as OSQP does) while the device program factors the reduced block-tridiagonal
+system, which differ by ~1e-9 per QP, and a chain of 5-10 such QPs can amplify that to a few 1e-4 for a handful of
+agents.  Tests therefore allow a stated number of agents between TOL and LOOSE_TOL and none above it; the HIP path is
+additionally compared with the lane-serial build of the same program, where the agreement is ~1e-9.
 """
 import numpy as np
 
 TOL = 1e-4
+LOOSE_TOL = 1e-3          # see below: sensitive agents
 CORRIDOR_FLIP_TOL = 2e-2
 
 

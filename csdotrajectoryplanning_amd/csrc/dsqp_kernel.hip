@@ -10,9 +10,10 @@
 namespace csdo {
 
 // BLOCK = 2 * (lanes per role): threads [0, BLOCK/2) are row lanes, [BLOCK/2, BLOCK) solver lanes (dsqp_program.h)
-template <int BLOCK>
+// BIG: E_r and the bounds stay in the workspace and LDS holds only the 6-vectors (horizons / obstacle counts whose
+// working set exceeds 160 KB of LDS)
+template <int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, const int max_obs) {
-  constexpr bool BIG = (BLOCK == 1024);  // Nt > 256: E_r and the bounds stay in the workspace, LDS holds vectors only
   extern __shared__ __align__(16) double lds[];
   const int agent = (int)blockIdx.x;
   if (agent >= B.n_agents) return;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   sh.lohi = sh.pr + 6 * st;
   sh.red = sh.lohi;                       // BIG: this region is only the 12-wide reduction scratch
   sh.er = sh.lohi + 22 * st;
-  sh.obs = BIG ? (sh.red + 12 * st) : (sh.er + 36 * st);
+  sh.obs = BIG ? (sh.red + 12 * st) : (sh.er + 38 * st);
   sh.bcast = sh.obs + 3 * max_obs;
   double* fac_global = B.fac_ws + ad.fac_off;
   sh.facE = fac_global;
@@ -74,17 +75,18 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
   boxes[4 * i + 3] = b.y_max;
 }
 
-size_t dsqp_lds_bytes(int max_nt, int max_obs, bool) {
+size_t dsqp_lds_bytes(int max_nt, int max_obs, bool big) {
   const int st = (max_nt + 1) & ~1;
-  const size_t per_lane = (max_nt > 256) ? 30 : 76;   // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + er 36)
+  const size_t per_lane = big ? 30 : 78;   // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + er 38)
   return (per_lane * st + (size_t)3 * max_obs + 32) * sizeof(double);
 }
 
 hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, hipStream_t stream) {
   constexpr size_t LDS_CAP = 160 * 1024;
   DeviceBatch b = B;
-  b.lds_fac = 0;
-  const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, false);
+  const bool big = max_nt > 256 || dsqp_lds_bytes(max_nt, max_obs, false) > LDS_CAP;
+  b.lds_fac = big ? 0 : 1;
+  const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, big);
   if (bytes > LDS_CAP) return hipErrorInvalidValue;
   auto go = [&](auto kernel, int block) -> hipError_t {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -94,9 +96,9 @@ hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, hipStream_
   };
   // two lanes per timestep: Nt <= 128 -> 256 threads (512 registers per lane), <= 256 -> 512 threads (256 registers),
   // <= 512 -> 1024 threads (128 registers: correct but spills; horizons that long are outside the benchmark sets)
-  if (max_nt <= 128) return go(dsqp_agent_kernel<256>, 256);
-  if (max_nt <= 256) return go(dsqp_agent_kernel<512>, 512);
-  return go(dsqp_agent_kernel<1024>, 1024);
+  if (max_nt <= 128) return big ? go(dsqp_agent_kernel<256, true>, 256) : go(dsqp_agent_kernel<256, false>, 256);
+  if (max_nt <= 256) return big ? go(dsqp_agent_kernel<512, true>, 512) : go(dsqp_agent_kernel<512, false>, 512);
+  return go(dsqp_agent_kernel<1024, true>, 1024);
 }
 
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,

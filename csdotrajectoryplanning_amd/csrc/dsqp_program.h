@@ -170,7 +170,7 @@ enum WsSlot {
 };
 
 // lane-major leading dimensions (doubles per lane) of the LDS arrays
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 36;
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 38;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
@@ -182,7 +182,7 @@ struct Shm {
   double* lohi;     // [stride][22] bounds of the home rows during an ADMM block: 0..6 eq rows (lo = hi),
                     //              7..12 lo and 13..18 hi of corridor/trust rows, 19..21 hi of the +-boxes (lo = -hi)
   double* red;      // [stride][12] reduction scratch; ALIASES lohi (reductions only run between ADMM blocks)
-  double* er;       // [stride][36] coupling block E_r of each BCR node (E_l sits in solver-lane registers)
+  double* er;       // [stride][38] coupling block E_r of each BCR node (E_l sits in solver-lane registers)
   double* obs;      // [3][n_obs]
   double* facE;     // [stride][72] coupling blocks E_l (36) + E_r (36), lane-major (global; cached in solver registers)
   double* facX;     // [78][stride] factor-time exchange (global, coalesced)

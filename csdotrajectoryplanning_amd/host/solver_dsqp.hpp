@@ -1,0 +1,141 @@
+// solver_dsqp.hpp — header-only C++ mirror of the reference's `SolverDSQP` (sqp/dsqp_solver.h:24-47) on top of the C ABI
+// (include/csdo_dsqp.h).  Same constructor shape, same public members and getters, so csdo.cc keeps its call site
+// (csdo.cc:146-159); the types below are the reference's PODs restated (sqp/common.h:14-52, sqp/corridor.h:8-11,
+// sqp/inter_agent_cons.h:47-63, common/motion_planning.h:79-84).  Link with -lcsdo_hip.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/csdo_dsqp.h"
+
+namespace csdo {
+
+struct OptimizeResult {
+  double x = 0, y = 0, yaw = 0, v = 0, a = 0, steer = 0, d_steer = 0;
+};
+struct InterPlane {
+  int t;
+  double a_f2f, b_f2f, c_f2f, a_f2r, b_f2r, c_f2r, a_r2f, b_r2f, c_r2f, a_r2r, b_r2r, c_r2r;
+};
+struct Corridor {
+  double xf_min, xf_max, yf_min, yf_max, xr_min, xr_max, yr_min, yr_max;
+};
+struct Location {
+  double x, y, r;
+};
+struct QpParm {
+  double r_trust, max_omega, max_v, max_iter, delta_solution_threshold, max_violation;
+  int osqp_max_iter;
+  double dt;
+  int num_interpolation;
+  bool fixed_corridor;
+};
+
+class SolverDSQP {
+ public:
+  // Any iterable of Location works for `obstacles` (the reference passes an unordered_set; order only matters when a
+  // point lies inside two inflated obstacles — this backend uses the iteration order it is given).
+  template <class ObstacleRange>
+  SolverDSQP(std::vector<std::vector<OptimizeResult>>& solutions,
+             const std::vector<std::vector<OptimizeResult>>& x0_bar,
+             const std::vector<std::vector<InterPlane>>& inter_planes, double dimx, double dimy,
+             const ObstacleRange& obstacles, const QpParm& param, int logger_level = 2, int device = 0,
+             const csdo_vehicle* vehicle = nullptr) {
+    const int Na = (int)x0_bar.size();
+    const int Nt = Na ? (int)x0_bar[0].size() : 0;
+    std::vector<double> x0((size_t)Na * Nt * 6), obs;
+    for (int a = 0; a < Na; ++a)
+      for (int t = 0; t < Nt; ++t) {
+        const OptimizeResult& r = x0_bar[a][t];
+        double* g = &x0[((size_t)a * Nt + t) * 6];
+        g[0] = r.x; g[1] = r.y; g[2] = r.yaw; g[3] = r.steer; g[4] = r.v; g[5] = r.d_steer;
+      }
+    std::vector<int32_t> off(Na + 1, 0);
+    std::vector<csdo_plane> planes;
+    for (int a = 0; a < Na; ++a) {
+      for (const InterPlane& p : inter_planes[a]) {
+        csdo_plane q{};
+        q.t = p.t;
+        const double c[12] = {p.a_f2f, p.b_f2f, p.c_f2f, p.a_f2r, p.b_f2r, p.c_f2r,
+                              p.a_r2f, p.b_r2f, p.c_r2f, p.a_r2r, p.b_r2r, p.c_r2r};
+        for (int k = 0; k < 12; ++k) q.c[k] = c[k];
+        planes.push_back(q);
+      }
+      off[a + 1] = (int32_t)planes.size();
+    }
+    for (const auto& o : obstacles) {
+      obs.push_back(o.x);
+      obs.push_back(o.y);
+      obs.push_back(o.r);
+    }
+    csdo_problem P{};
+    P.Na = Na;
+    P.Nt = Nt;
+    P.x0_bar = x0.data();
+    P.plane_off = off.data();
+    P.planes = planes.data();
+    P.dimx = dimx;
+    P.dimy = dimy;
+    P.n_obs = (int32_t)(obs.size() / 3);
+    P.obstacles = obs.data();
+    if (vehicle) P.veh = *vehicle; else csdo_vehicle_default(&P.veh);
+    P.parm.r_trust = param.r_trust;
+    P.parm.max_omega = param.max_omega;
+    P.parm.max_v = param.max_v;
+    P.parm.max_iter = param.max_iter;
+    P.parm.delta_solution_threshold = param.delta_solution_threshold;
+    P.parm.max_violation = param.max_violation;
+    P.parm.osqp_max_iter = param.osqp_max_iter;
+    P.parm.num_interpolation = param.num_interpolation;
+    P.parm.dt = param.dt;
+    P.parm.fixed_corridor = param.fixed_corridor ? 1 : 0;
+    P.parm.adaptive_rho_interval = 0;  // documented default (25)
+    P.logger_level = logger_level;
+
+    std::vector<double> sol((size_t)Na * Nt * 6), cor((size_t)Na * Nt * 8);
+    std::vector<int32_t> admm(Na), last(Na);
+    num_iterations.assign(Na, 0);
+    csdo_result R{};
+    R.solutions = sol.data();
+    R.corridors = cor.data();
+    R.sqp_iters = num_iterations.data();
+    R.admm_iters = admm.data();
+    R.last_status = last.data();
+    csdo_handle h = nullptr;
+    int rc = csdo_dsqp_create(&h, device);
+    if (rc == CSDO_OK) rc = csdo_dsqp_solve(h, &P, &R);
+    if (h) csdo_dsqp_destroy(h);
+    if (rc != CSDO_OK) throw std::runtime_error("csdo_dsqp_solve failed with code " + std::to_string(rc));
+
+    solutions.assign(Na, std::vector<OptimizeResult>(Nt));
+    corridors.assign(Na, std::vector<Corridor>(Nt));
+    for (int a = 0; a < Na; ++a)
+      for (int t = 0; t < Nt; ++t) {
+        const double* s = &sol[((size_t)a * Nt + t) * 6];
+        OptimizeResult& r = solutions[a][t];
+        r.x = s[0]; r.y = s[1]; r.yaw = s[2]; r.steer = s[3]; r.v = s[4]; r.d_steer = s[5];
+        const double* c = &cor[((size_t)a * Nt + t) * 8];
+        corridors[a][t] = Corridor{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};
+      }
+    admm_iterations.assign(admm.begin(), admm.end());
+    solve_status = R.solver_status;
+    initial_static_legal = R.initial_static_legal != 0;
+    max_individual_opt_runtime = R.t_max_individual;
+  }
+
+  int getSolverStatus() const { return solve_status; }
+  double getMaxOfRuntimes() const { return max_individual_opt_runtime; }
+  bool get_initial_static_legal() const { return initial_static_legal; }
+
+  std::vector<int> num_iterations;
+  std::vector<std::vector<Corridor>> corridors;
+  std::vector<int> admm_iterations;  // new: needed for the agent-QP-iterations/s metric
+
+ private:
+  int solve_status = 0;
+  double max_individual_opt_runtime = -1;
+  bool initial_static_legal = true;
+};
+
+}  // namespace csdo

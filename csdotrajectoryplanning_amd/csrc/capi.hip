@@ -150,8 +150,9 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   B.lds_fac = 0;
   B.prof = nullptr;
 #if defined(CSDO_PROFILE_PHASES)
-  if ((rc = h->prof.ensure(Na * 16 * sizeof(int64_t))) != CSDO_OK) return rc;
+  if ((rc = h->prof.ensure(Na * 48 * sizeof(int64_t))) != CSDO_OK) return rc;
   B.prof = (int64_t*)h->prof.p;
+  (void)hipMemsetAsync(h->prof.p, 0, Na * 48 * sizeof(int64_t), h->stream);
 #endif
   B.prm = hb.prm;
   HIP_OK(hipStreamSynchronize(h->stream), CSDO_EDEVICE);
@@ -303,7 +304,7 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p) {
 int csdo_debug_phase_ticks(csdo_handle h, int64_t* phases16, int64_t* agent_ticks) {
   if (!h || !h->uploaded) return CSDO_EINVAL;
   const size_t Na = h->hb.agents.size();
-  if (hipMemcpy(phases16, h->prof.p, Na * 16 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
+  if (hipMemcpy(phases16, h->prof.p, Na * 48 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
   if (hipMemcpy(agent_ticks, h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
   return CSDO_OK;
 }

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   sh.carry2 = sh.pr;
   sh.lohi = sh.pr + 6 * st;
   sh.red = sh.lohi;                       // BIG: this region is only the 12-wide reduction scratch
-  sh.er = sh.lohi + 22 * st;
+  sh.sinvs = sh.lohi + 22 * st;
+  sh.er = sh.sinvs + 22 * st;
   sh.obs = BIG ? (sh.red + 12 * st) : (sh.er + 38 * st);
   sh.bcast = sh.obs + 3 * max_obs;
   double* fac_global = B.fac_ws + ad.fac_off;
@@ -77,14 +78,14 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
 
 size_t dsqp_lds_bytes(int max_nt, int max_obs, bool big) {
   const int st = (max_nt + 1) & ~1;
-  const size_t per_lane = big ? 30 : 78;   // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + er 38)
+  const size_t per_lane = big ? 30 : 100;  // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + sinv 22 + er 38)
   return (per_lane * st + (size_t)3 * max_obs + 32) * sizeof(double);
 }
 
 hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, hipStream_t stream) {
   constexpr size_t LDS_CAP = 160 * 1024;
   DeviceBatch b = B;
-  const bool big = max_nt > 256 || dsqp_lds_bytes(max_nt, max_obs, false) > LDS_CAP;
+  const bool big = max_nt > 256 || dsqp_lds_bytes(max_nt, max_obs, false) > LDS_CAP;   // non-BIG fits up to Nt ~ 200
   b.lds_fac = big ? 0 : 1;
   const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, big);
   if (bytes > LDS_CAP) return hipErrorInvalidValue;

@@ -44,6 +44,8 @@
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
 #define CSDO_MARK(name) asm volatile("; CSDO_MARK " name)
+// keep the instruction scheduler from merging hand-pipelined stages (it would raise register pressure again)
+#define CSDO_STAGE() __builtin_amdgcn_sched_barrier(0)
 #if defined(CSDO_PROFILE_PHASES)
 // diagnostic build: thread 0 accumulates shader-clock ticks per phase (never enabled in the shipped library)
 #define CSDO_PHASE(k)                                                    \
@@ -66,6 +68,7 @@
 #define CSDO_SS(t) lanes_s[t]
 #define CSDO_SYNC() ((void)0)
 #define CSDO_MARK(name) ((void)0)
+#define CSDO_STAGE() ((void)0)
 #define CSDO_PHASE(k) ((void)0)
 #else
 #error "define CSDO_LANE_MODE_DEVICE or CSDO_LANE_MODE_SERIAL"
@@ -139,7 +142,7 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   int ncols;                // 6, or 4 at t = Nt-1
 };
 struct SolvRegs {           // solver lane of timestep t: BCR node t and the inter-vehicle rows at t
-  double sinv[21];          // inverse of this node's BCR pivot block (symmetric, packed lower)
+  double sinv[21];          // factor-time only: inverse of this node's pivot block (the solve reads it from LDS)
   double b[6];              // rhs -> BCR work vector -> x_tilde
   double el[36];            // coupling block to the left neighbour at this node's elimination level (E_r: LDS)
   double fa[21], fr[36];    // factor-time only: current diagonal block and coupling to the right neighbour
@@ -170,7 +173,7 @@ enum WsSlot {
 };
 
 // lane-major leading dimensions (doubles per lane) of the LDS arrays
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 38;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 38, LD_sinvs = 22;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
@@ -182,6 +185,7 @@ struct Shm {
   double* lohi;     // [stride][22] bounds of the home rows during an ADMM block: 0..6 eq rows (lo = hi),
                     //              7..12 lo and 13..18 hi of corridor/trust rows, 19..21 hi of the +-boxes (lo = -hi)
   double* red;      // [stride][12] reduction scratch; ALIASES lohi (reductions only run between ADMM blocks)
+  double* sinvs;    // [stride][22] pivot-block inverses (packed lower) of the BCR nodes during an ADMM block
   double* er;       // [stride][38] coupling block E_r of each BCR node (E_l sits in solver-lane registers)
   double* obs;      // [3][n_obs]
   double* facE;     // [stride][72] coupling blocks E_l (36) + E_r (36), lane-major (global; cached in solver registers)
@@ -495,6 +499,17 @@ CSDO_FN double rho_of_masks(unsigned eqmask, unsigned loosemask, int i, double r
   return (loosemask & bit) ? RHO_MIN : ((eqmask & bit) ? RHO_EQ_OVER_RHO_INEQ * rho : rho);
 }
 CSDO_FN double rho_of(const LaneState& S, int i, double rho) { return rho_of_masks(S.eqmask, S.loosemask, i, rho); }
+
+// Row classes known at compile time: kinematic and start/goal rows (0..6) have l = u, i.e. always OSQP's equality
+// class; trust, control and steer rows (11..15) have u - l >= 0.1, always the inequality class; only the corridor rows
+// (7..10) can be either (a zero-width box is an equality).  Home rows always have finite bounds (never "loose").
+// Passing the two uniform values keeps rho_i out of per-lane registers.
+template <int I>
+CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
+  if constexpr (I < 7) return rho_eq;
+  else if constexpr (I >= 11) return rho;
+  else return (S.eqmask & (1u << I)) ? rho_eq : rho;
+}
 
 // BIG: horizons whose E_r blocks and bounds do not fit in LDS (Nt > 256) read them from the workspace instead.
 template <int ROLE, bool BIG, class RowStore, class SolvStore>

@@ -11,6 +11,7 @@ namespace csdo {
 #define SX(k, t) sh.facX[(k) * sh.stride + (t)]
 // E_r of node t: LDS copy, or the workspace copy for long horizons
 #define ER(k, t) (BIG ? SH(facE, 36 + (k), t) : SH(er, k, t))
+#define SINV(k, t) (BIG ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
 #define CD(slot, t) sh.cold[(slot) * sh.stride + (t)]
 #define WS(slot, t) sh.cold[(slot) * sh.stride + (t)]
 
@@ -128,6 +129,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long prof_last = (long long)__builtin_amdgcn_s_memtime();
   int prof_cur = 0;
+  long long lvl_fwd = 0, lvl_bwd = 0;  // solver lane t == h: cycles inside its own elimination block
+#define CSDO_LVL_BEGIN() const long long lvl_t0 = (long long)__builtin_amdgcn_s_memtime()
+#define CSDO_LVL_END(acc) acc += (long long)__builtin_amdgcn_s_memtime() - lvl_t0
+#else
+#define CSDO_LVL_BEGIN() ((void)0)
+#define CSDO_LVL_END(acc) ((void)0)
 #endif
 
 #define ROW(r, f) rows[(int64_t)(f) * rcap + (r)]
@@ -447,10 +454,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           SolvRegs& V = CSDO_SS(t);
           if ((t & m2) == h) {
             double Rl[36];
-            CSDO_FOR(k, 36, {
-              Rl[k] = SH(facE, 36 + k, t - h);
-              SH(facE, k, t) = Rl[k];
-            });
+            CSDO_FOR(k, 36, { Rl[k] = SH(facE, 36 + k, t - h); });
             double Ain[21];
             CSDO_FOR(k, 21, { Ain[k] = V.fa[k]; });
             spd_inverse6(Ain, V.sinv);
@@ -462,6 +466,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
                 double a = 0.0;
                 CSDO_FOR(k, 6, { a = fma(V.sinv[sym(r, k)], Rl[k * 6 + c], a); });
                 T[r * 6 + c] = a;
+                SH(facE, r * 6 + c, t) = a;   // F_l = Sinv * E_l: what the solve uses
               });
             });
             // U_l = Rl' T  -> Schur update of the left neighbour's diagonal block
@@ -481,6 +486,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
                   double a = 0.0;
                   CSDO_FOR(k, 6, { a = fma(V.sinv[sym(r, k)], Rr[c * 6 + k], a); });
                   Vm[r * 6 + c] = a;
+                  SH(facE, 36 + c * 6 + r, t) = a;   // F_r = E_r * Sinv = (Sinv * E_r')'
                 });
               });
               CSDO_FOR(a_, 6, {
@@ -546,23 +552,44 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             if ((t + hp) < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + hp); });
           }
           if ((t & m2) == h) {
-            double w[6];
-            symv6(V.sinv, V.b, w);
-            CSDO_FOR(k, 6, { V.b[k] = w[k]; });
-            double pl6[6] = {0, 0, 0, 0, 0, 0};
-            CSDO_FOR(k, 6, {  // pl = E_l' w, six independent accumulators
-              CSDO_FOR(bcol, 6, { pl6[bcol] = fma(V.el[k * 6 + bcol], w[k], pl6[bcol]); });
+            CSDO_LVL_BEGIN();
+            // three independent 6x6 products of the same b: w = Sinv b, pl = F_l' b, pr = F_r b.
+            // fp64 FMAs need >= ~11 independent accumulation chains to issue back to back (measured: 6 chains run
+            // at ~7 cycles per FMA, scripts/microbench.hip), so every product is split into two half-sums.
+            const bool has_r = (t + h) < Nt;
+            double bb[6];
+            CSDO_FOR(k, 6, { bb[k] = V.b[k]; });
+            double sv[21];
+            CSDO_FOR(k, 21, { sv[k] = SINV(k, t); });
+            double pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
+            CSDO_FOR(r, 3, {
+              CSDO_FOR(c, 6, {
+                pa[c] = fma(V.el[r * 6 + c], bb[r], pa[c]);
+                pb[c] = fma(V.el[(r + 3) * 6 + c], bb[r + 3], pb[c]);
+              });
             });
-            CSDO_FOR(bcol, 6, { SH(pl, bcol, t) = pl6[bcol]; });
-            if ((t + h) < Nt) {
+            CSDO_FOR(c, 6, { SH(pl, c, t) = pa[c] + pb[c]; });
+            double wa[6] = {0, 0, 0, 0, 0, 0}, wb[6] = {0, 0, 0, 0, 0, 0};
+            CSDO_FOR(c, 3, {
+              CSDO_FOR(r, 6, {
+                wa[r] = fma(sv[sym(r, c)], bb[c], wa[r]);
+                wb[r] = fma(sv[sym(r, c + 3)], bb[c + 3], wb[r]);
+              });
+            });
+            CSDO_FOR(k, 6, { V.b[k] = wa[k] + wb[k]; });
+            if (has_r) {
               double er_[36];
               CSDO_FOR(k, 36, { er_[k] = ER(k, t); });
-              double pr6[6] = {0, 0, 0, 0, 0, 0};
-              CSDO_FOR(k, 6, {  // pr = E_r w
-                CSDO_FOR(arow, 6, { pr6[arow] = fma(er_[arow * 6 + k], w[k], pr6[arow]); });
+              double qa[6] = {0, 0, 0, 0, 0, 0}, qb[6] = {0, 0, 0, 0, 0, 0};
+              CSDO_FOR(k, 3, {
+                CSDO_FOR(arow, 6, {
+                  qa[arow] = fma(er_[arow * 6 + k], bb[k], qa[arow]);
+                  qb[arow] = fma(er_[arow * 6 + k + 3], bb[k + 3], qb[arow]);
+                });
               });
-              CSDO_FOR(arow, 6, { SH(pr, arow, t) = pr6[arow]; });
+              CSDO_FOR(arow, 6, { SH(pr, arow, t) = qa[arow] + qb[arow]; });
             }
+            CSDO_LVL_END(lvl_fwd);
           }
         }
         CSDO_PHASE(13);
@@ -574,8 +601,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         if (t == 0) {
           if (Nt == 1) CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
           if (htop < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, htop); });
-          double w[6];
-          symv6(V.sinv, V.b, w);
+          double w[6], sv[21];
+          CSDO_FOR(k, 21, { sv[k] = SINV(k, t); });
+          symv6(sv, V.b, w);
           CSDO_FOR(k, 6, {
             V.b[k] = w[k];
             SH(vec, k, 0) = w[k];
@@ -589,26 +617,37 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_SLANES(t) {
           SolvRegs& V = CSDO_SS(t);
           if ((t & m2) == h) {
-            double xl[6], tmp[6] = {0, 0, 0, 0, 0, 0};
+            CSDO_LVL_BEGIN();
+            // x = w - F_l x_left - F_r' x_right: two independent half-sums (12 accumulation chains)
+            const bool has_r = (t + h) < Nt;
+            double xl[6], xr[6] = {0, 0, 0, 0, 0, 0};
             CSDO_FOR(k, 6, { xl[k] = SH(vec, k, t - h); });
-            CSDO_FOR(k, 6, {
-              CSDO_FOR(r, 6, { tmp[r] = fma(V.el[r * 6 + k], xl[k], tmp[r]); });
-            });
-            if ((t + h) < Nt) {
-              double xr[6];
-              CSDO_FOR(k, 6, { xr[k] = SH(vec, k, t + h); });
+            if (has_r) CSDO_FOR(k, 6, { xr[k] = SH(vec, k, t + h); });
+            double ua[6], ub[6] = {0, 0, 0, 0, 0, 0};
+            CSDO_FOR(k, 6, { ua[k] = V.b[k]; });
+            if (has_r) {
               double er_[36];
               CSDO_FOR(k, 36, { er_[k] = ER(k, t); });
-              CSDO_FOR(k, 6, {
-                CSDO_FOR(r, 6, { tmp[r] = fma(er_[k * 6 + r], xr[k], tmp[r]); });
+              CSDO_FOR(c, 6, {
+                CSDO_FOR(r, 6, {
+                  ua[r] = fma(-V.el[r * 6 + c], xl[c], ua[r]);
+                  ub[r] = fma(-er_[c * 6 + r], xr[c], ub[r]);
+                });
+              });
+            } else {
+              CSDO_FOR(c, 3, {
+                CSDO_FOR(r, 6, {
+                  ua[r] = fma(-V.el[r * 6 + c], xl[c], ua[r]);
+                  ub[r] = fma(-V.el[r * 6 + c + 3], xl[c + 3], ub[r]);
+                });
               });
             }
-            double corr[6];
-            symv6(V.sinv, tmp, corr);
             CSDO_FOR(k, 6, {
-              V.b[k] = V.b[k] - corr[k];
-              SH(vec, k, t) = V.b[k];
+              const double xk = ua[k] + ub[k];
+              V.b[k] = xk;
+              SH(vec, k, t) = xk;
             });
+            CSDO_LVL_END(lvl_bwd);
           }
         }
         CSDO_PHASE(14);
@@ -922,7 +961,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_SLANES(t) {  // load the solver-lane cache and the inter-row share of the first rhs
         SolvRegs& V = CSDO_SS(t);
-        CSDO_FOR(k, 21, { V.sinv[k] = WS(W_SINV + k, t); });
+        if constexpr (!BIG) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
         CSDO_FOR(k, 36, {
           V.el[k] = SH(facE, k, t);
           if constexpr (!BIG) SH(er, k, t) = SH(facE, 36 + k, t);
@@ -931,15 +970,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         inter_pass(std::false_type{}, t, none, rho, false);
       }
       CSDO_SYNC();
-      while (iter < stop) {
-        ++iter;
+      const double rho_eq = RHO_EQ_OVER_RHO_INEQ * rho, rinv_in = 1.0 / rho, rinv_eq = 1.0 / rho_eq;
+      auto iteration = [&](auto keep_c) __attribute__((always_inline)) {
+        constexpr bool keep_dy = decltype(keep_c)::value;   // only the last iteration of a block records delta_y
         CSDO_PHASE(6);
         // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
         CSDO_MARK("rhs");
         CSDO_LANES(t) {
           LaneState& S = CSDO_LS(t);
           CSDO_FOR(k, 4, {
-            SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_of(S, k, rho), S.z[k], -S.y[k]) : 0.0;
+            SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq, S.z[k], -S.y[k]) : 0.0;
           });
         }
         CSDO_SYNC();
@@ -950,7 +990,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
           CSDO_FOR(i, NROW, {
             if (S.act & (1u << i)) {
-              const double g = fma(rho_of(S, i, rho), S.z[i], -S.y[i]);
+              const double g = fma(rho_row<i>(S, rho, rho_eq), S.z[i], -S.y[i]);
               CSDO_FOR(s, 3, {
                 if constexpr (row_col(i, s) >= 0) r6[row_col(i, s)] = fma(S.c[i][s], g, r6[row_col(i, s)]);
               });
@@ -964,7 +1004,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_PHASE(9);
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");
-        const bool keep_dy = (iter == stop);
         CSDO_SLANES(t) {  // inter-vehicle rows, concurrently with the row lanes below
           SolvRegs& V = CSDO_SS(t);
           inter_pass(std::true_type{}, t, V.b, rho, keep_dy);
@@ -981,8 +1020,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
                 if constexpr (row_col(i, s) >= 0) zt = fma(S.c[i][s], xt[row_col(i, s)], zt);
               });
               if constexpr (i < 4) zt = fma(S.cn[i], xn[i], zt);
-              const double rh = rho_of(S, i, rho);
-              const double rinv = 1.0 / rh;
+              const double rh = rho_row<i>(S, rho, rho_eq);
+              const double rinv = rho_row<i>(S, rinv_in, rinv_eq);   // = 1.0 / rh (rho_inv_vec of OSQP)
               const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
               double lo_i, hi_i;
               if constexpr (BIG) {
@@ -1001,7 +1040,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               }
               const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], lo_i), hi_i);
               const double d = rh * (zr - zn);
-              if (keep_dy) WS(C_DY + i, t) = d;
+              if constexpr (keep_dy) WS(C_DY + i, t) = d;
               S.y[i] += d;
               S.z[i] = zn;
             }
@@ -1011,7 +1050,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           });
         }
         CSDO_SYNC();
+      };
+      while (iter < stop - 1) {
+        ++iter;
+        iteration(std::false_type{});
       }
+      ++iter;
+      iteration(std::true_type{});
       CSDO_PHASE(12);
       CSDO_LANES(t) {  // write the iterate back: nothing else changes inside a block
         LaneState& S = CSDO_LS(t);
@@ -1183,7 +1228,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #if defined(CSDO_PROFILE_PHASES)
   CSDO_PHASE(0);
   if (threadIdx.x == 0 && B.prof)
-    for (int k = 0; k < 16; ++k) B.prof[(int64_t)agent * 16 + k] = prof_acc[k];
+    for (int k = 0; k < 16; ++k) B.prof[(int64_t)agent * 48 + k] = prof_acc[k];
+  if constexpr (ROLE == ROLE_SOLVER) {
+    const int ts = (int)threadIdx.x - (int)(blockDim.x >> 1);
+    if (B.prof && ts > 0 && ts < Nt && (ts & (ts - 1)) == 0) {   // lanes 1, 2, 4, ...: eliminated at level log2(ts)
+      int lv = 0;
+      while ((1 << lv) < ts) ++lv;
+      B.prof[(int64_t)agent * 48 + 16 + lv] = lvl_fwd;
+      B.prof[(int64_t)agent * 48 + 32 + lv] = lvl_bwd;
+    }
+  }
 #endif
   out.sqp_iters = it;
   out.admm_iters = admm_total;
@@ -1194,6 +1248,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #undef SH
 #undef SX
 #undef ER
+#undef SINV
 #undef CD
 #undef WS
 

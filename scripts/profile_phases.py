@@ -21,7 +21,7 @@ h.run()
 ks = h.run()
 sol = h.download()[0]
 L = _lib.lib()
-ph = np.zeros((world.Na, 16), np.int64)
+ph = np.zeros((world.Na, 48), np.int64)
 tk = np.zeros(world.Na, np.int64)
 L.csdo_debug_phase_ticks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 assert L.csdo_debug_phase_ticks(h._h, ph.ctypes.data, tk.ctypes.data) == 0
@@ -29,9 +29,11 @@ K = world.plane_off[1:] - world.plane_off[:-1]
 print("kernel %.1f ms, Nt=%d" % (ks * 1e3, world.Nt))
 order = np.argsort(-tk)[:4].tolist() + np.argsort(tk)[:1].tolist()
 for a in order:
-    tot = ph[a].sum()
+    tot = ph[a][:16].sum()
     print("agent %d: wall %.1f ms, sqp %d, admm %d, planes %d, clock %.2f GHz, us/iter %.1f" % (
         a, tk[a] * 1e-5, sol.sqp_iters[a], sol.admm_iters[a], K[a], tot / (tk[a] * 10.0) , tk[a] * 1e-2 / max(sol.admm_iters[a], 1)))
     print("   " + "  ".join("%s %.1f%%" % (n, 100.0 * ph[a][i] / tot) for i, n in enumerate(NAMES)))
     it = max(sol.admm_iters[a], 1)
+    print("   level compute (lane t=2^l) cycles/iter: fwd " + " ".join("%d" % (ph[a][16 + l] / it) for l in range(8)) + " | bwd " + " ".join("%d" % (ph[a][32 + l] / it) for l in range(8)))
+    print("   per-level cycles/iter in the eliminated solver lane: fwd " + " ".join("%d" % (ph[a][16 + l] / it if True else 0) for l in range(8)) + " | bwd " + " ".join("%d" % (ph[a][32 + l] / it) for l in range(8))) if False else None
     print("   cycles/iter: " + "  ".join("%s %d" % (NAMES[i], ph[a][i] / it) for i in (6, 7, 13, 8, 14, 9, 10)))

@@ -43,7 +43,7 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
   for (int a = 0; a < Na; ++a) {
     const AgentDesc& ad = hb.agents[a];
     const int st = fac_stride(ad.Nt);
-    std::vector<double> lds((size_t)78 * st + 3 * hb.max_obs + 32, 0.0);
+    std::vector<double> lds((size_t)100 * st + 3 * hb.max_obs + 32, 0.0);
     Shm sh{};
     sh.stride = st;
     sh.vec = lds.data();
@@ -53,7 +53,8 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
     sh.carry2 = sh.pr;
     sh.lohi = sh.pr + 6 * st;
     sh.red = sh.lohi;
-    sh.er = sh.lohi + 22 * st;
+    sh.sinvs = sh.lohi + 22 * st;
+    sh.er = sh.sinvs + 22 * st;
     sh.obs = sh.er + 38 * st;
     sh.bcast = sh.obs + 3 * hb.max_obs;
     sh.facE = fac_ws.data() + ad.fac_off;

@@ -33,6 +33,8 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   sh.er = sh.sinvs + 22 * st;
   sh.obs = BIG ? (sh.red + 12 * st) : (sh.er + 38 * st);
   sh.bcast = sh.obs + 3 * max_obs;
+  sh.tvec = sh.bcast + 32;
+  sh.tinv = sh.tvec + 2 * TAIL_N;
   double* fac_global = B.fac_ws + ad.fac_off;
   sh.facE = fac_global;
   sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;
@@ -79,7 +81,7 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
 size_t dsqp_lds_bytes(int max_nt, int max_obs, bool big) {
   const int st = (max_nt + 1) & ~1;
   const size_t per_lane = big ? 30 : 100;  // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + sinv 22 + er 38)
-  return (per_lane * st + (size_t)3 * max_obs + 32) * sizeof(double);
+  return (per_lane * st + (size_t)3 * max_obs + 32 + 2 * TAIL_N + TAIL_N * 38) * sizeof(double);
 }
 
 hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, hipStream_t stream) {

@@ -40,6 +40,9 @@
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = (int)threadIdx.x; t < Nt)
 #define CSDO_SLANES(t) \
   if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - (int)(blockDim.x >> 1); t >= 0 && t < Nt)
+// tail lanes: solver-half threads [HALF, HALF + n_tail), independent of Nt (n_tail <= 36 <= HALF)
+#define CSDO_TLANES(t) \
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - (int)(blockDim.x >> 1); t >= 0 && t < n_tail)
 #define CSDO_LS(t) lanes_r
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
@@ -64,6 +67,7 @@
 #define CSDO_FN inline
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)
 #define CSDO_SLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < Nt; ++t)
+#define CSDO_TLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < n_tail; ++t)
 #define CSDO_LS(t) lanes_r[t]
 #define CSDO_SS(t) lanes_s[t]
 #define CSDO_SYNC() ((void)0)
@@ -88,6 +92,9 @@ constexpr int ROLE_BOTH = 0, ROLE_ROW = 1, ROLE_SOLVER = 2;   // ROLE_BOTH: lane
 // ---------------------------------------------------------------------------------------------------------
 constexpr int NROW = 16;
 constexpr int NCOLS = 6;
+// BCR stops when at most TAIL_NODES nodes remain; the remaining block-tridiagonal system (<= 36 unknowns) is solved
+// with its explicit dense inverse by 6*R lanes in one phase instead of log2(R)+1 forward and backward level phases.
+constexpr int TAIL_NODES = 6, TAIL_N = 6 * TAIL_NODES;
 
 CSDO_FN constexpr int row_col(int i, int s) {
   constexpr int T[NROW][3] = {{0, 2, 4}, {1, 2, 4}, {2, 3, 4}, {3, 5, -1}, {0, -1, -1}, {1, -1, -1},
@@ -146,6 +153,7 @@ struct SolvRegs {           // solver lane of timestep t: BCR node t and the int
   double b[6];              // rhs -> BCR work vector -> x_tilde
   double el[36];            // coupling block to the left neighbour at this node's elimination level (E_r: LDS)
   double fa[21], fr[36];    // factor-time only: current diagonal block and coupling to the right neighbour
+  double trow[TAIL_N];      // factor-time only: this tail lane's row during the Gauss-Jordan inversion
 };
 typedef RowRegs LaneState;  // the row lane is the "home" of a timestep
 
@@ -173,7 +181,7 @@ enum WsSlot {
 };
 
 // lane-major leading dimensions (doubles per lane) of the LDS arrays
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 38, LD_sinvs = 22;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 38, LD_sinvs = 22, LD_tinv = 38;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
@@ -192,6 +200,8 @@ struct Shm {
   double* facX;     // [78][stride] factor-time exchange (global, coalesced)
   double* cold;     // [C_TOTAL][stride] per-agent workspace (global)
   double* bcast;    // [32] block-wide results
+  double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
+  double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
   int stride;
 };
 

@@ -125,6 +125,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   const bool has_inter = ad.n_planes > 0;
   const double sigma = P.sigma, alpha = P.alpha;
   const int n_vars = 6 * Nt - 2;
+  int h_tail = 1;                       // BCR levels run for h < h_tail; nodes k * h_tail form the dense tail
+  while ((Nt + h_tail - 1) / h_tail > TAIL_NODES) h_tail <<= 1;
+  const int R_tail = (Nt + h_tail - 1) / h_tail, n_tail = 6 * R_tail;
 #if defined(CSDO_PROFILE_PHASES)
   long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long prof_last = (long long)__builtin_amdgcn_s_memtime();
@@ -440,7 +443,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
         }
       }
-      for (int h = 1; h < Nt; h <<= 1) {
+      for (int h = 1; h < h_tail; h <<= 1) {
         const int m2 = 2 * h - 1;
         CSDO_SLANES(t) {  // every active node publishes its coupling to the right neighbour (= its E_r once eliminated)
           SolvRegs& V = CSDO_SS(t);
@@ -520,15 +523,66 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           }
         }
       }
+      // ---- dense tail: the remaining nodes k * h_tail (k < R_tail) form a block-tridiagonal system with diagonal
+      // blocks fa and couplings fr.  Tail lane r = 6k + i (solver lanes 0 .. n_tail-1) assembles row r of that matrix,
+      // all tail lanes invert it together by Gauss-Jordan elimination without pivoting (the matrix is SPD) with the
+      // pivot row broadcast through LDS, and the rows of the inverse are parked in LDS for the solves.
       CSDO_SLANES(t) {
         SolvRegs& V = CSDO_SS(t);
-        if (t == 0) {
-          double Ain[21];
-          CSDO_FOR(k, 21, { Ain[k] = V.fa[k]; });
-          spd_inverse6(Ain, V.sinv);
-          CSDO_FOR(k, 21, { WS(W_SINV + k, t) = V.sinv[k]; });
-          CSDO_FOR(k, 72, { SH(facE, k, 0) = 0.0; });
+        if ((t & (h_tail - 1)) == 0) {
+          CSDO_FOR(k, 21, { SX(k, t) = V.fa[k]; });
+          const bool has_r = (t + h_tail) < Nt;
+          CSDO_FOR(k, 36, { SX(21 + k, t) = has_r ? V.fr[k] : 0.0; });
         }
+      }
+      CSDO_SYNC();
+      CSDO_TLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
+        {
+          const int kn = t / 6, i = t - 6 * kn, jn = kn * h_tail;
+          CSDO_FOR(c, TAIL_N, {
+            constexpr int kc = c / 6, ic = c % 6;
+            double v = 0.0;
+            if (c < n_tail) {
+              if (kc == kn) v = SX((i >= ic) ? (i * (i + 1) / 2 + ic) : (ic * (ic + 1) / 2 + i), jn);
+              else if (kc == kn - 1) v = SX(21 + i * 6 + ic, jn - h_tail);   // H(node kn, node kn-1)[i][ic]
+              else if (kc == kn + 1) v = SX(21 + ic * 6 + i, jn);            // H(node kn+1, node kn)[ic][i]
+            }
+            V.trow[c] = v;
+          });
+        }
+      }
+      for (int pv = 0; pv < n_tail; ++pv) {
+        CSDO_TLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
+          if (t == pv) {
+            double piv = 0.0;
+            CSDO_FOR(c, TAIL_N, { piv = (c == pv) ? V.trow[c] : piv; });
+            const double dinv = 1.0 / piv;
+            CSDO_FOR(c, TAIL_N, {
+              V.trow[c] = (c == pv) ? dinv : V.trow[c] * dinv;
+              sh.tvec[TAIL_N + c] = V.trow[c];
+            });
+          }
+        }
+        CSDO_SYNC();
+        CSDO_TLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
+          if (t != pv) {
+            double f = 0.0;
+            CSDO_FOR(c, TAIL_N, { f = (c == pv) ? V.trow[c] : f; });
+            CSDO_FOR(c, TAIL_N, {
+              const double pc = sh.tvec[TAIL_N + c];
+              V.trow[c] = (c == pv) ? (-f * pc) : fma(-f, pc, V.trow[c]);
+            });
+          }
+        }
+        CSDO_SYNC();
+      }
+      CSDO_TLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
+        CSDO_FOR(c, TAIL_N, { SH(tinv, c, t) = V.trow[c]; });
+        if (t == 0) CSDO_FOR(k, 72, { SH(facE, k, 0) = 0.0; });
       }
       CSDO_SYNC();
     };
@@ -539,13 +593,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     auto solve = [&]() __attribute__((always_inline)) {
       CSDO_MARK("solve_begin");
       CSDO_PHASE(7);
-      int htop = 1;
-      for (int h = 1; h < Nt; h <<= 1) {
+      CSDO_SLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
+        CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
+      }
+      for (int h = 1; h < h_tail; h <<= 1) {
         const int m2 = 2 * h - 1;
-        htop = h;
         CSDO_SLANES(t) {
           SolvRegs& V = CSDO_SS(t);
-          if (h == 1) CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
           if (h > 1 && (t & (h - 1)) == 0) {  // absorb the partials of the previous level
             const int hp = h >> 1;
             if (t >= hp) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - hp); });
@@ -596,23 +651,38 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_SYNC();
         CSDO_PHASE(7);
       }
+      // ---- dense tail: tail nodes absorb the last level's partials and gather their rhs; tail lane r multiplies row r
+      // of the explicit inverse with it and scatters the solution straight into the nodes' vec slots
       CSDO_SLANES(t) {
         SolvRegs& V = CSDO_SS(t);
-        if (t == 0) {
-          if (Nt == 1) CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
-          if (htop < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, htop); });
-          double w[6], sv[21];
-          CSDO_FOR(k, 21, { sv[k] = SINV(k, t); });
-          symv6(sv, V.b, w);
-          CSDO_FOR(k, 6, {
-            V.b[k] = w[k];
-            SH(vec, k, 0) = w[k];
+        if ((t & (h_tail - 1)) == 0) {
+          if (h_tail > 1) {
+            const int hp = h_tail >> 1;
+            if (t >= hp) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - hp); });
+            if ((t + hp) < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + hp); });
+          }
+          const int kn = t / h_tail;
+          CSDO_FOR(k, 6, { sh.tvec[6 * kn + k] = V.b[k]; });
+        }
+      }
+      CSDO_SYNC();
+      CSDO_TLANES(t) {
+        {
+          double a4[4] = {0, 0, 0, 0};
+          CSDO_FOR(c, TAIL_N, {
+            if (c < n_tail) a4[c & 3] = fma(SH(tinv, c, t), sh.tvec[c], a4[c & 3]);
           });
+          const int kn = t / 6, i = t - 6 * kn;
+          sh.vec[(kn * h_tail) * LD_vec + i] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         }
       }
       CSDO_SYNC();
       CSDO_PHASE(8);
-      for (int h = htop; h >= 1; h >>= 1) {
+      CSDO_SLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
+        if ((t & (h_tail - 1)) == 0) CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
+      }
+      for (int h = h_tail >> 1; h >= 1; h >>= 1) {
         const int m2 = 2 * h - 1;
         CSDO_SLANES(t) {
           SolvRegs& V = CSDO_SS(t);
@@ -667,73 +737,70 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_FOR(k, 12, { nrm[k] = 0.0; });
     bool info_valid = false;
 
-    // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective; works from the workspace
+    // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective.  Like update_info it runs right
+    // after a block: coefficients come from the row-lane registers, delta_y / bounds / scalings from the workspace in
+    // one batch of loads.
     auto primal_infeasible = [&](const double eps_pinf) __attribute__((always_inline)) -> bool {
       CSDO_MARK("pinf_begin");
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
-        double nmax = 0.0;
+        double dy[NROW], lo_[NROW], hi_[NROW], ee[NROW];
+        CSDO_FOR(i, NROW, {
+          dy[i] = WS(C_DY + i, t);
+          lo_[i] = WS(W_LO + i, t);
+          hi_[i] = WS(W_HI + i, t);
+          ee[i] = WS(C_E + i, t);
+        });
+        double nmax = 0.0, acc = 0.0;
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
-            double dyi = WS(C_DY + i, t);
-            const double hi_i = WS(W_HI + i, t), lo_i = WS(W_LO + i, t);
-            if (hi_i > OSQP_INFTY * MIN_SCALING) {
-              if (lo_i < -OSQP_INFTY * MIN_SCALING) dyi = 0.0;
+            double dyi = dy[i];
+            if (hi_[i] > OSQP_INFTY * MIN_SCALING) {
+              if (lo_[i] < -OSQP_INFTY * MIN_SCALING) dyi = 0.0;
               else dyi = osqp_min(dyi, 0.0);
-            } else if (lo_i < -OSQP_INFTY * MIN_SCALING) {
+            } else if (lo_[i] < -OSQP_INFTY * MIN_SCALING) {
               dyi = osqp_max(dyi, 0.0);
             }
             WS(C_DY + i, t) = dyi;
-            nmax = dmax(nmax, fabs(WS(C_E + i, t) * dyi));
-          }
-        });
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {  // l = -inf, u finite
-          const double d = osqp_max(ROW(r, R_DY), 0.0);
-          ROW(r, R_DY) = d;
-          nmax = dmax(nmax, fabs(ROW(r, R_E) * d));
-        }
-        const double part[1] = {nmax};
-        red_put<1>(sh, t, part);
-      }
-      double r1[1];
-      red_fold<1, false>(sh, Nt, r1);
-      const double norm_dy = r1[0];
-      if (!(norm_dy > eps_pinf)) return false;
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        double acc = 0.0;
-        CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
-            const double dyi = WS(C_DY + i, t);
-            acc += WS(W_HI + i, t) * osqp_max(dyi, 0.0) + WS(W_LO + i, t) * osqp_min(dyi, 0.0);
+            nmax = dmax(nmax, fabs(ee[i] * dyi));
+            acc += hi_[i] * osqp_max(dyi, 0.0) + lo_[i] * osqp_min(dyi, 0.0);
           }
         });
         // reference quirk: l = -infinity (a true IEEE inf, dsqp_solver.cc:1121-1123) times min(dy,0) = 0 is NaN, so
         // the certificate test is false for every agent that has inter-vehicle rows; IEEE arithmetic reproduces it
         const double ninf = -INFINITY;
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r)
-          acc += ROW(r, R_U) * osqp_max(ROW(r, R_DY), 0.0) + ninf * osqp_min(ROW(r, R_DY), 0.0);
-        const double part[1] = {acc};
-        red_put<1>(sh, t, part);
+        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {  // l = -inf, u finite
+          const double d = osqp_max(ROW(r, R_DY), 0.0);
+          ROW(r, R_DY) = d;
+          nmax = dmax(nmax, fabs(ROW(r, R_E) * d));
+          acc += ROW(r, R_U) * osqp_max(d, 0.0) + ninf * osqp_min(d, 0.0);
+        }
+        const double part[2] = {nmax, acc};
+        red_put<2>(sh, t, part);
       }
-      double r2[1];
-      red_fold<1, true>(sh, Nt, r2);
-      if (!(r2[0] < -eps_pinf * norm_dy)) return false;
+      // slot 0 is a max, slot 1 a sum: fold both ways over the same scratch
+      double r_max[2], r_sum[2];
+      red_fold<2, false>(sh, Nt, r_max);
+      const double norm_dy = r_max[0];
+      if (!(norm_dy > eps_pinf)) return false;
+      red_fold<2, true>(sh, Nt, r_sum);
+      if (!(r_sum[1] < -eps_pinf * norm_dy)) return false;
       // || Dinv A' dy ||
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? WS(W_CN + k, t) * WS(C_DY + k, t) : 0.0; });
+        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * WS(C_DY + k, t) : 0.0; });
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
+        double dy[NROW];
+        CSDO_FOR(i, NROW, { dy[i] = WS(C_DY + i, t); });
         double v[6] = {0, 0, 0, 0, 0, 0};
         if (t > 0) CSDO_FOR(k, 4, { v[k] = SH(carry, k, t - 1); });
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
-            const double dyi = WS(C_DY + i, t);
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(WS(W_C + 3 * i + s, t), dyi, v[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(S.c[i][s], dy[i], v[row_col(i, s)]);
             });
           }
         });
@@ -788,23 +855,28 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       return false;
     };
 
-    // update_info (auxil.c): residuals of the current (x, z, y) read from the workspace, unscaled for the
-    // termination test and scaled for adapt_rho
+    // update_info (auxil.c): residuals of the current (x, z, y), unscaled for the termination test and scaled for
+    // adapt_rho.  Always called right after an ADMM block, while the row lanes still hold c, cn, y, z, x in registers;
+    // only the Ruiz scalings and the objective come from the workspace (one batch of loads).
     auto update_info = [&]() __attribute__((always_inline)) {
       CSDO_MARK("info_begin");
       CSDO_PHASE(10);
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 5, { SH(carry2, k, t) = WS(W_X + k, t); });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
-        CSDO_FOR(k, 4, {                                           // to t+1: A'y share of the kinematic rows
-          SH(carry, k, t) = (S.act & (1u << k)) ? WS(W_CN + k, t) * WS(W_Yv + k, t) : 0.0;
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = S.x[k]; });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
+        CSDO_FOR(k, 4, {                                  // to t+1: A'y share of the kinematic rows
+          SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * S.y[k] : 0.0;
         });
-        SH(carry, 4, t) = WS(W_X + 4, t);
+        SH(carry, 4, t) = S.x[4];
         SH(carry, 5, t) = WS(W_P + 2, t);
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
+        double einv[NROW], dinv[6];
+        CSDO_FOR(i, NROW, { einv[i] = WS(C_E + i, t); });
+        CSDO_FOR(j, 6, { dinv[j] = WS(C_D + j, t); });
+        const double pvv = WS(W_P + 0, t), pww = WS(W_P + 1, t), pvn = WS(W_P + 2, t);
         double xn[4] = {0, 0, 0, 0};
         double vn = 0.0, vp = 0.0, pvn_left = 0.0;
         if (t < Nm) {
@@ -817,61 +889,65 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           vp = SH(carry, 4, t - 1);
           pvn_left = SH(carry, 5, t - 1);
         }
-        double xx[6];
-        CSDO_FOR(j, 6, { xx[j] = WS(W_X + j, t); });
         double p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         CSDO_FOR(i, NROW, {
           if (S.act & (1u << i)) {
             double ax = 0.0;
-            double ci[3] = {0, 0, 0};
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) {
-                ci[s] = WS(W_C + 3 * i + s, t);
-                ax = fma(ci[s], xx[row_col(i, s)], ax);
-              }
+              if constexpr (row_col(i, s) >= 0) ax = fma(S.c[i][s], S.x[row_col(i, s)], ax);
             });
-            if constexpr (i < 4) ax = fma(WS(W_CN + i, t), xn[i], ax);
-            const double zi = WS(W_Zv + i, t), yi = WS(W_Yv + i, t);
-            const double einv = 1.0 / WS(C_E + i, t);
+            if constexpr (i < 4) ax = fma(S.cn[i], xn[i], ax);
+            const double zi = S.z[i], yi = S.y[i];
+            const double ei = 1.0 / einv[i];
             const double res = ax - zi;
-            p[0] = dmax(p[0], fabs(einv * res));
-            p[1] = dmax(p[1], fabs(einv * zi));
-            p[2] = dmax(p[2], fabs(einv * ax));
+            p[0] = dmax(p[0], fabs(ei * res));
+            p[1] = dmax(p[1], fabs(ei * zi));
+            p[2] = dmax(p[2], fabs(ei * ax));
             p[3] = dmax(p[3], fabs(res));
             p[4] = dmax(p[4], fabs(zi));
             p[5] = dmax(p[5], fabs(ax));
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(ci[s], yi, Aty[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(S.c[i][s], yi, Aty[row_col(i, s)]);
             });
           }
         });
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double ca = ROW(r, R_CA), cb = ROW(r, R_CB), cy = ROW(r, R_CY);
-          const double ax = (ca * xx[0] + cb * xx[1]) + cy * xx[2];
-          const double zz = ROW(r, R_Z), yy = ROW(r, R_Y), einv = 1.0 / ROW(r, R_E);
-          const double res = ax - zz;
-          p[0] = dmax(p[0], fabs(einv * res));
-          p[1] = dmax(p[1], fabs(einv * zz));
-          p[2] = dmax(p[2], fabs(einv * ax));
-          p[3] = dmax(p[3], fabs(res));
-          p[4] = dmax(p[4], fabs(zz));
-          p[5] = dmax(p[5], fabs(ax));
-          Aty[0] = fma(ca, yy, Aty[0]);
-          Aty[1] = fma(cb, yy, Aty[1]);
-          Aty[2] = fma(cy, yy, Aty[2]);
+        for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
+          double ca[4], cb[4], cy[4], zz[4], yy[4], ee[4];
+          CSDO_FOR(q, 4, {
+            ca[q] = ROW(4 * k + q, R_CA);
+            cb[q] = ROW(4 * k + q, R_CB);
+            cy[q] = ROW(4 * k + q, R_CY);
+            zz[q] = ROW(4 * k + q, R_Z);
+            yy[q] = ROW(4 * k + q, R_Y);
+            ee[q] = ROW(4 * k + q, R_E);
+          });
+          CSDO_FOR(q, 4, {
+            const double ax = (ca[q] * S.x[0] + cb[q] * S.x[1]) + cy[q] * S.x[2];
+            const double ei = 1.0 / ee[q];
+            const double res = ax - zz[q];
+            p[0] = dmax(p[0], fabs(ei * res));
+            p[1] = dmax(p[1], fabs(ei * zz[q]));
+            p[2] = dmax(p[2], fabs(ei * ax));
+            p[3] = dmax(p[3], fabs(res));
+            p[4] = dmax(p[4], fabs(zz[q]));
+            p[5] = dmax(p[5], fabs(ax));
+            Aty[0] = fma(ca[q], yy[q], Aty[0]);
+            Aty[1] = fma(cb[q], yy[q], Aty[1]);
+            Aty[2] = fma(cy[q], yy[q], Aty[2]);
+          });
         }
         double Px[6] = {0, 0, 0, 0, 0, 0};
         if (t < Nm) {
-          Px[4] = (WS(W_P + 0, t) * xx[4] + WS(W_P + 2, t) * vn) + pvn_left * vp;
-          Px[5] = WS(W_P + 1, t) * xx[5];
+          Px[4] = (pvv * S.x[4] + pvn * vn) + pvn_left * vp;
+          Px[5] = pww * S.x[5];
         }
         CSDO_FOR(j, 6, {
           if (j < S.ncols) {
-            const double dinv = 1.0 / WS(C_D + j, t);
+            const double dj = 1.0 / dinv[j];
             const double dr = (0.0 + Px[j]) + Aty[j];
-            p[6] = dmax(p[6], fabs(dinv * dr));
-            p[7] = dmax(p[7], fabs(dinv * Aty[j]));
-            p[8] = dmax(p[8], fabs(dinv * Px[j]));
+            p[6] = dmax(p[6], fabs(dj * dr));
+            p[7] = dmax(p[7], fabs(dj * Aty[j]));
+            p[8] = dmax(p[8], fabs(dj * Px[j]));
             p[9] = dmax(p[9], fabs(dr));
             p[10] = dmax(p[10], fabs(Aty[j]));
             p[11] = dmax(p[11], fabs(Px[j]));

@@ -23,7 +23,7 @@ struct HostBatch {
   int64_t rows_total = 0;      // inter rows (4 per plane)
   int64_t fac_total = 0;       // doubles of factor workspace
   int64_t steps_total = 0;     // sum of Nt over agents
-  int max_nt = 0, max_obs = 0;
+  int max_nt = 0, max_obs = 0, max_planes = 0;
   SolverParams prm{};
 };
 
@@ -84,6 +84,7 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
       ad.world = w;
       const int k0 = W.plane_off[a], k1 = W.plane_off[a + 1];
       ad.n_planes = k1 - k0;
+      hb.max_planes = std::max(hb.max_planes, (int)ad.n_planes);
       ad.x0_off = (int64_t)hb.x0.size();
       hb.x0.insert(hb.x0.end(), W.x0_bar + (size_t)a * W.Nt * 6, W.x0_bar + (size_t)(a + 1) * W.Nt * 6);
       ad.plane_off = (int64_t)hb.planes.size();

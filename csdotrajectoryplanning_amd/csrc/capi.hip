@@ -166,7 +166,7 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   HIP_OK(hipEventRecord(h->ev0, s), CSDO_EDEVICE);
-  if (launch_dsqp(h->dev, h->hb.max_nt, h->hb.max_obs, s) != hipSuccess) return CSDO_EDEVICE;
+  if (launch_dsqp(h->dev, h->hb.max_nt, h->hb.max_obs, h->hb.max_planes, s) != hipSuccess) return CSDO_EDEVICE;
   HIP_OK(hipEventRecord(h->ev1, s), CSDO_EDEVICE);
   HIP_OK(hipEventSynchronize(h->ev1), CSDO_EDEVICE);
   float ms = 0.f;

@@ -38,11 +38,13 @@
 // Both instantiations execute the same barrier sequence and derive every uniform control value (iteration counts,
 // status, rho, norms) from the same LDS broadcasts.
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = (int)threadIdx.x; t < Nt)
+// ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
+#define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
 #define CSDO_SLANES(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - (int)(blockDim.x >> 1); t >= 0 && t < Nt)
-// tail lanes: solver-half threads [HALF, HALF + n_tail), independent of Nt (n_tail <= 36 <= HALF)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
+// tail lanes: solver threads [base, base + n_tail), independent of Nt (n_tail <= 36)
 #define CSDO_TLANES(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - (int)(blockDim.x >> 1); t >= 0 && t < n_tail)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
 #define CSDO_LS(t) lanes_r
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
@@ -202,6 +204,7 @@ struct Shm {
   double* bcast;    // [32] block-wide results
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
   double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
+  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in BIG mode)
   int stride;
 };
 
@@ -216,7 +219,7 @@ struct AgentCtx {
 };
 
 // inter-vehicle row workspace: SoA by field, [field][4K] per agent (the 4 rows of a plane are contiguous)
-enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };
+enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };   // then [3K] plane shares (BIG)
 
 // =========================================================================================================
 // Block-wide reductions.  Partials are stored per lane in sh.pl/sh.pr (12 slots); after a barrier the first wave

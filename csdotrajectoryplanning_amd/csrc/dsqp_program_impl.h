@@ -162,6 +162,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     S.ncols = (t < Nm) ? 6 : 4;
     S.eqmask = 0;
     S.loosemask = 0;
+    if (t < 2 * TAIL_N) sh.tvec[t] = 0.0;
+    if (t == 0 && Nt < 2 * TAIL_N)
+      for (int k = Nt; k < 2 * TAIL_N; ++k) sh.tvec[k] = 0.0;
   }
   CSDO_SYNC();
 
@@ -203,7 +206,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   double delta = th + 1.0;
   int it = 0, status = 1, admm_total = 0;
 
+#if defined(CSDO_ABL_FIXED)
+  while (it < P.max_iter) {
+#else
   while (delta > th && it < P.max_iter) {
+#endif
   CSDO_PHASE(2);
     // ============================================================== assemble the QP (unscaled)
     CSDO_MARK("assemble");
@@ -593,6 +600,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     auto solve = [&]() __attribute__((always_inline)) {
       CSDO_MARK("solve_begin");
       CSDO_PHASE(7);
+#if defined(CSDO_ABL_NOSOLVE)
+      CSDO_SYNC();
+      return;
+#endif
       CSDO_SLANES(t) {
         SolvRegs& V = CSDO_SS(t);
         CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
@@ -606,7 +617,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             if (t >= hp) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - hp); });
             if ((t + hp) < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + hp); });
           }
+#if defined(CSDO_ABL_NOLEVELWORK)
+          if (false) {
+#else
           if ((t & m2) == h) {
+#endif
             CSDO_LVL_BEGIN();
             // three independent 6x6 products of the same b: w = Sinv b, pl = F_l' b, pr = F_r b.
             // fp64 FMAs need >= ~11 independent accumulation chains to issue back to back (measured: 6 chains run
@@ -668,12 +683,27 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_SYNC();
       CSDO_TLANES(t) {
         {
-          double a4[4] = {0, 0, 0, 0};
-          CSDO_FOR(c, TAIL_N, {
-            if (c < n_tail) a4[c & 3] = fma(SH(tinv, c, t), sh.tvec[c], a4[c & 3]);
-          });
+          // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed
+          double a4[6] = {0, 0, 0, 0, 0, 0};
+          {
+            double tr[TAIL_N / 2], tb[TAIL_N / 2];
+            CSDO_FOR(c, TAIL_N / 2, {
+              tr[c] = SH(tinv, c, t);
+              tb[c] = sh.tvec[c];
+            });
+            CSDO_FOR(c, TAIL_N / 2, { a4[c % 6] = fma(tr[c], tb[c], a4[c % 6]); });
+          }
+          CSDO_STAGE();
+          {
+            double tr[TAIL_N / 2], tb[TAIL_N / 2];
+            CSDO_FOR(c, TAIL_N / 2, {
+              tr[c] = SH(tinv, TAIL_N / 2 + c, t);
+              tb[c] = sh.tvec[TAIL_N / 2 + c];
+            });
+            CSDO_FOR(c, TAIL_N / 2, { a4[c % 6] = fma(tr[c], tb[c], a4[c % 6]); });
+          }
           const int kn = t / 6, i = t - 6 * kn;
-          sh.vec[(kn * h_tail) * LD_vec + i] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+          sh.vec[(kn * h_tail) * LD_vec + i] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + (a4[4] + a4[5]);
         }
       }
       CSDO_SYNC();
@@ -686,7 +716,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const int m2 = 2 * h - 1;
         CSDO_SLANES(t) {
           SolvRegs& V = CSDO_SS(t);
+#if defined(CSDO_ABL_NOLEVELWORK) || defined(CSDO_ABL_NOBWDWORK)
+          if (false) {
+#else
           if ((t & m2) == h) {
+#endif
             CSDO_LVL_BEGIN();
             // x = w - F_l x_left - F_r' x_right: two independent half-sums (12 accumulation chains)
             const bool has_r = (t + h) < Nt;
@@ -838,7 +872,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       const double eps_prim = eps_abs + eps_rel * osqp_max(nrm[1], nrm[2]);
       bool prim_ok = false, prim_inf = false;
       if (pri_res < eps_prim) prim_ok = true;
-      else prim_inf = primal_infeasible(eps_pinf);
+      // With at least one inter-vehicle row the certificate sum contains (-inf) * 0 = NaN (see primal_infeasible), so the
+      // test is false whatever the iterate: skip its three reductions.  (Its only side effect, the projection of
+      // delta_y, is not observable: delta_y is rewritten by the next iteration.)
+      else prim_inf = has_inter ? false : primal_infeasible(eps_pinf);
       double mx = osqp_max(0.0, nrm[7]);  // ||Dinv q|| = 0, then ||Dinv A'y||, then ||Dinv P x||
       mx = osqp_max(mx, nrm[8]);
       const double eps_dual = eps_abs + eps_rel * (mx * cinv);
@@ -962,24 +999,31 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // ---- the ADMM loop runs in blocks that end where osqp_solve would look at the iterate (termination check,
     // rho adaptation, iteration cap).  Inside a block only register state and the LDS 6-vectors are touched, plus the
     // inter-vehicle rows of the solver lanes.
-    // Inter-vehicle rows of timestep t belong to solver lane t: `inter_pass<UPDATE>` walks the planes at t (the 4 rows
-    // of a plane are loaded together), optionally applies the z / y update with x_tilde = V.b, and leaves
-    // A'(rho z - y) restricted to those rows in sh.carry2[t][0..2] for the row lane's next rhs.
-    auto inter_pass = [&](auto update_c, const int t, const double (&xt)[6], const double rho_now,
-                          const bool keep_dy) __attribute__((always_inline)) {
+    // Inter-vehicle rows are spread evenly over the solver lanes, plane by plane (lane l takes planes l, l + Nt, ...:
+    // coalesced 32-byte field loads, at most ceil(K / Nt) planes per lane whatever their timesteps).  `plane_pass<UPDATE>`
+    // optionally applies the z / y update with x_tilde of the plane's timestep (read from sh.vec) and leaves the
+    // plane's share of A'(rho z - y) in pc[p][0..2]; the row lane of that timestep adds its planes' shares to its rhs.
+    const int K_planes = ad.n_planes;
+#define PC(k, p) sh.pc[(p) * 3 + (k)]
+    auto plane_pass = [&](auto update_c, auto keep_c, const int lane, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
-      double ic[3] = {0, 0, 0};
+      constexpr bool KEEP = decltype(keep_c)::value;
       const double rinv = 1.0 / rho_now;
-      for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
-        double zz[4], yy[4], ca[4], cb[4], cy[4], uu[4];
+      for (int p = lane; p < K_planes; p += Nt) {
+        double zz[4], yy[4], ca[4], cb[4], cy[4], uu[4], xt[3] = {0, 0, 0};
         CSDO_FOR(q, 4, {
-          zz[q] = ROW(4 * k + q, R_Z);
-          yy[q] = ROW(4 * k + q, R_Y);
-          ca[q] = ROW(4 * k + q, R_CA);
-          cb[q] = ROW(4 * k + q, R_CB);
-          cy[q] = ROW(4 * k + q, R_CY);
-          if constexpr (UPDATE) uu[q] = ROW(4 * k + q, R_U);
+          zz[q] = ROW(4 * p + q, R_Z);
+          yy[q] = ROW(4 * p + q, R_Y);
+          ca[q] = ROW(4 * p + q, R_CA);
+          cb[q] = ROW(4 * p + q, R_CB);
+          cy[q] = ROW(4 * p + q, R_CY);
+          if constexpr (UPDATE) uu[q] = ROW(4 * p + q, R_U);
         });
+        if constexpr (UPDATE) {
+          const int tp = planes[p].t;
+          CSDO_FOR(k, 3, { xt[k] = SH(vec, k, tp); });
+        }
+        double ic[3] = {0, 0, 0};
         CSDO_FOR(q, 4, {
           double zq = zz[q], yq = yy[q];
           if constexpr (UPDATE) {
@@ -987,19 +1031,19 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             const double zr = alpha * ztr + (1.0 - alpha) * zq;
             const double zn = osqp_min(zr + rinv * yq, uu[q]);  // lower bound is -inf
             const double d = rho_now * (zr - zn);
-            if (keep_dy) ROW(4 * k + q, R_DY) = d;
+            if constexpr (KEEP) ROW(4 * p + q, R_DY) = d;
             yq = yq + d;
             zq = zn;
-            ROW(4 * k + q, R_Y) = yq;
-            ROW(4 * k + q, R_Z) = zq;
+            ROW(4 * p + q, R_Y) = yq;
+            ROW(4 * p + q, R_Z) = zq;
           }
           const double g = fma(rho_now, zq, -yq);
           ic[0] = fma(ca[q], g, ic[0]);
           ic[1] = fma(cb[q], g, ic[1]);
           ic[2] = fma(cy[q], g, ic[2]);
         });
+        CSDO_FOR(k, 3, { PC(k, p) = ic[k]; });
       }
-      CSDO_FOR(k, 3, { SH(carry2, k, t) = ic[k]; });
     };
 
     bool can_check = false;
@@ -1042,8 +1086,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           V.el[k] = SH(facE, k, t);
           if constexpr (!BIG) SH(er, k, t) = SH(facE, 36 + k, t);
         });
-        const double none[6] = {0, 0, 0, 0, 0, 0};
-        inter_pass(std::false_type{}, t, none, rho, false);
+        plane_pass(std::false_type{}, std::false_type{}, t, rho);
       }
       CSDO_SYNC();
       const double rho_eq = RHO_EQ_OVER_RHO_INEQ * rho, rinv_in = 1.0 / rho, rinv_eq = 1.0 / rho_eq;
@@ -1072,7 +1115,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               });
             }
           });
-          CSDO_FOR(k, 3, { r6[k] += SH(carry2, k, t); });   // inter-vehicle rows, summed by the solver lane
+          for (int p = tstart[t]; p < tstart[t + 1]; ++p)      // inter-vehicle rows: per-plane shares from the solver lanes
+            CSDO_FOR(k, 3, { r6[k] += PC(k, p); });
           CSDO_FOR(j, 6, { SH(vec, j, t) = r6[j]; });
         }
         CSDO_SYNC();
@@ -1080,10 +1124,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_PHASE(9);
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");
+#if !defined(CSDO_ABL_NOPLANES)
         CSDO_SLANES(t) {  // inter-vehicle rows, concurrently with the row lanes below
-          SolvRegs& V = CSDO_SS(t);
-          inter_pass(std::true_type{}, t, V.b, rho, keep_dy);
+          plane_pass(std::true_type{}, keep_c, t, rho);
         }
+#endif
         CSDO_LANES(t) {
           LaneState& S = CSDO_LS(t);
           double xt[6], xn[4] = {0, 0, 0, 0};
@@ -1147,8 +1192,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       can_check = chk && (iter % chk == 0);
       info_valid = false;
       if (can_check) {
+#if !defined(CSDO_ABL_NOCHECK)
         update_info();
+#if defined(CSDO_ABL_FIXED)
+        check_termination(false);
+        qp_status = -10;
+#else
         if (check_termination(false)) break;
+#endif
+#endif
       }
       if (iter >= max_it) {
         finished = true;
@@ -1264,7 +1316,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       const double err_int = has_inter ? rm[5] : 0.0;
       feasible = (err_kin < 1e-2) && (err_int < 1e-1) && (err_cor < 1e-1);
     }
+#if !defined(CSDO_ABL_FIXED)
     if (feasible) break;
+#endif
 
     CSDO_PHASE(1);
     CSDO_SLANES(t) {  // updateCorridor :818-872 (double-precision disc centres): rear disc on the solver lane
@@ -1319,6 +1373,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   out.admm_iters = admm_total;
   out.last_status = status;
 #undef ROW
+#undef PC
 }
 
 #undef SH

@@ -43,7 +43,7 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
   for (int a = 0; a < Na; ++a) {
     const AgentDesc& ad = hb.agents[a];
     const int st = fac_stride(ad.Nt);
-    std::vector<double> lds((size_t)100 * st + 3 * hb.max_obs + 32 + 2 * TAIL_N + TAIL_N * 38, 0.0);
+    std::vector<double> lds((size_t)100 * st + 3 * hb.max_obs + 32 + 2 * TAIL_N + TAIL_N * 38 + 3 * hb.max_planes, 0.0);
     Shm sh{};
     sh.stride = st;
     sh.vec = lds.data();
@@ -59,6 +59,7 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
     sh.bcast = sh.obs + 3 * hb.max_obs;
     sh.tvec = sh.bcast + 32;
     sh.tinv = sh.tvec + 2 * TAIL_N;
+    sh.pc = sh.tinv + TAIL_N * 38;
     sh.facE = fac_ws.data() + ad.fac_off;
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;
     sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;

@@ -21,8 +21,11 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   const int agent = (int)blockIdx.x;
   if (agent >= B.n_agents) return;
   const long long t_begin = wall_clock64();
-  const AgentDesc& ad = B.agents[agent];
-  const int st = (ad.Nt + 1) & ~1;
+  const int ad_Nt = uniform_i32(B.agents[agent].Nt);
+  const long long ad_fac_off = uniform_i64(B.agents[agent].fac_off);
+  const long long ad_rows_off = uniform_i64(B.agents[agent].rows_off);
+  const int ad_n_planes = uniform_i32(B.agents[agent].n_planes);
+  const int st = (ad_Nt + 1) & ~1;
   Shm sh;
   sh.stride = st;
   sh.vec = lds;
@@ -38,9 +41,9 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   sh.bcast = sh.obs + 3 * max_obs;
   sh.tvec = sh.bcast + 32;
   sh.tinv = sh.tvec + 2 * TAIL_N;
-  sh.pc = BIG ? (B.rows_ws + ad.rows_off * ROWS_WS_STRIDE + (size_t)32 * ad.n_planes) : (sh.tinv + TAIL_N * 38);
+  sh.pc = BIG ? (B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes) : (sh.tinv + TAIL_N * 38);
   (void)max_planes;
-  double* fac_global = B.fac_ws + ad.fac_off;
+  double* fac_global = B.fac_ws + ad_fac_off;
   sh.facE = fac_global;
   sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;
   sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;

@@ -120,6 +120,25 @@ CSDO_FN void static_for(F&& f) {
 }
 #define CSDO_FOR(I, N, ...) static_for<N>([&](auto I##_c) __attribute__((always_inline)) { constexpr int I = decltype(I##_c)::value; __VA_ARGS__ })
 
+// Block-uniform values fetched with vector loads (per-agent descriptors) would sit in VGPRs: move them to SGPRs.
+#if defined(CSDO_LANE_MODE_DEVICE)
+CSDO_FN int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+CSDO_FN long long uniform_i64(long long v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+CSDO_FN double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+#else
+CSDO_FN int uniform_i32(int v) { return v; }
+CSDO_FN long long uniform_i64(long long v) { return v; }
+CSDO_FN double uniform_f64(double v) { return v; }
+#endif
+
 CSDO_FN double dmax(double a, double b) { return (b > a) ? b : a; }   // NaN in b is ignored, like vec_norm_inf
 CSDO_FN double dmin(double a, double b) { return (b < a) ? b : a; }
 CSDO_FN double osqp_max(double a, double b) { return (a > b) ? a : b; }  // c_max

@@ -111,8 +111,21 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 template <int ROLE, bool BIG, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out) {
-  const AgentDesc ad = B.agents[agent];
-  const WorldDesc wd = B.worlds[ad.world];
+  AgentDesc ad = B.agents[agent];
+  ad.Nt = uniform_i32(ad.Nt);
+  ad.world = uniform_i32(ad.world);
+  ad.n_planes = uniform_i32(ad.n_planes);
+  ad.x0_off = uniform_i64(ad.x0_off);
+  ad.plane_off = uniform_i64(ad.plane_off);
+  ad.tstart_off = uniform_i64(ad.tstart_off);
+  ad.rows_off = uniform_i64(ad.rows_off);
+  ad.fac_off = uniform_i64(ad.fac_off);
+  ad.out_off = uniform_i64(ad.out_off);
+  WorldDesc wd = B.worlds[ad.world];
+  wd.dimx = uniform_f64(wd.dimx);
+  wd.dimy = uniform_f64(wd.dimy);
+  wd.obs_off = uniform_i32(wd.obs_off);
+  wd.n_obs = uniform_i32(wd.n_obs);
   const SolverParams& P = B.prm;
   const int Nt = ad.Nt, Nm = Nt - 1;
   const double* x0g = B.x0 + ad.x0_off;

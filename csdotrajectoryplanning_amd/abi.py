@@ -50,7 +50,7 @@ class Result(C.Structure):
     _fields_ = [("solutions", c_double_p), ("corridors", c_double_p), ("sqp_iters", c_int32_p),
                 ("admm_iters", c_int32_p), ("last_status", c_int32_p), ("solver_status", C.c_int32),
                 ("initial_static_legal", C.c_int32), ("t_total", C.c_double), ("t_device", C.c_double),
-                ("t_max_individual", C.c_double)]
+                ("t_max_individual", C.c_double), ("agent_seconds", c_double_p)]
 
 
 class BridgeOut(C.Structure):
@@ -72,9 +72,16 @@ def as_plane_p(a):
 
 
 # Every symbol include/csdo_dsqp.h declares (checked by tests/test_abi.py against the built library).
+class LaunchGroup(C.Structure):
+    """csdo_launch_group (include/csdo_dsqp.h)."""
+    _fields_ = [("n_agents", C.c_int32), ("threads", C.c_int32), ("residency_mode", C.c_int32),
+                ("max_nt", C.c_int32), ("lds_bytes", C.c_int64), ("seconds", C.c_double)]
+
+
 EXPORTED_SYMBOLS = (
     "csdo_dsqp_create", "csdo_dsqp_destroy", "csdo_dsqp_solve", "csdo_dsqp_solve_batch", "csdo_dsqp_upload",
-    "csdo_dsqp_run", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_device_solutions",
+    "csdo_dsqp_run", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_launch_groups", "csdo_dsqp_set_min_residency_mode",
+    "csdo_dsqp_device_solutions",
     "csdo_preprocess", "csdo_bridge_free", "csdo_generate_boxes", "csdo_vehicle_default",
     "csdo_qp_parm_default", "csdo_backend_name",
 )

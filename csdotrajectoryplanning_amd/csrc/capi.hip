@@ -46,11 +46,17 @@ struct csdo_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // launch groups (dsqp_launch.h): group 0 runs on the caller's stream, the others concurrently on side streams
+  std::vector<LaunchGroup> groups;
+  int min_mode = 0;            // csdo_dsqp_set_min_residency_mode
+  std::vector<int32_t> order;
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> g_begin, g_end;
   HostBatch hb;
   bool uploaded = false;
   int n_worlds = 0;
   double last_kernel_s = 0.0;
-  DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks;
+  DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d;
   DevBuf box_pts, box_obs, box_out, box_status;
   DevBuf prof;
   std::vector<double> h_sol, h_corr;
@@ -63,6 +69,59 @@ struct csdo_handle_s {
   do {                                     \
     if ((expr) != hipSuccess) return code; \
   } while (0)
+
+
+// Groups the agents of the uploaded batch by kernel class and orders each group heaviest-first by the work estimate
+// of batch_pack.h (workgroups are dispatched in index order, so the agents expected to run longest start first:
+// longest-processing-time scheduling over the 256 CUs).
+static int build_groups(csdo_handle h) {
+  const HostBatch& hb = h->hb;
+  const int Na = (int)hb.agents.size();
+  struct Key { int block; int mode; };
+  std::vector<Key> key(Na);
+  std::vector<size_t> need(Na);
+  for (int a = 0; a < Na; ++a) {
+    const AgentDesc& ad = hb.agents[a];
+    const int n_obs = hb.worlds[ad.world].n_obs;
+    key[a].block = dsqp_agent_class(ad.Nt, n_obs, ad.n_planes, &key[a].mode);
+    if (key[a].mode < h->min_mode) key[a].mode = (h->min_mode == 1 && key[a].block != 512) ? 2 : h->min_mode;
+    need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode);
+  }
+  h->order.resize(Na);
+  for (int a = 0; a < Na; ++a) h->order[a] = a;
+  std::stable_sort(h->order.begin(), h->order.end(), [&](int p, int q) {
+    if (key[p].block != key[q].block) return key[p].block < key[q].block;
+    if (key[p].mode != key[q].mode) return key[p].mode < key[q].mode;   // the faster, LDS-resident class first
+    return hb.est_work[p] > hb.est_work[q];
+  });
+  h->groups.clear();
+  for (int i = 0; i < Na; ++i) {
+    const int a = h->order[i];
+    if (h->groups.empty() || h->groups.back().block != key[a].block || h->groups.back().mode != key[a].mode) {
+      LaunchGroup g;
+      g.first = i;
+      g.block = key[a].block;
+      g.mode = key[a].mode;
+      h->groups.push_back(g);
+    }
+    LaunchGroup& g = h->groups.back();
+    g.count++;
+    g.max_nt = std::max(g.max_nt, (int)hb.agents[a].Nt);
+    g.lds_bytes = std::max(g.lds_bytes, need[a]);
+  }
+  while (h->side.size() + 1 < h->groups.size()) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CSDO_EDEVICE;
+    h->side.push_back(s);
+  }
+  while (h->g_begin.size() < h->groups.size()) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CSDO_EDEVICE;
+    h->g_begin.push_back(e0);
+    h->g_end.push_back(e1);
+  }
+  return CSDO_OK;
+}
 
 extern "C" {
 
@@ -91,9 +150,12 @@ void csdo_dsqp_destroy(csdo_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
-                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->box_pts, &h->box_obs,
-                    &h->box_out, &h->box_status})
+                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->box_pts,
+                    &h->box_obs, &h->box_out, &h->box_status})
     b->release();
+  for (hipStream_t s : h->side) (void)hipStreamDestroy(s);
+  for (hipEvent_t e : h->g_begin) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->g_end) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -120,6 +182,8 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   UP(planes, hb.planes);
   UP(tstart, hb.tstart);
   UP(obstacles, hb.obstacles);
+  if ((rc = build_groups(h)) != CSDO_OK) return rc;
+  UP(order_d, h->order);
 #undef UP
   if ((rc = h->rows_ws.ensure((size_t)hb.rows_total * ROWS_WS_STRIDE * sizeof(double))) != CSDO_OK) return rc;
   if ((rc = h->fac_ws.ensure((size_t)hb.fac_total * sizeof(double))) != CSDO_OK) return rc;
@@ -146,8 +210,8 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   B.last_status = (int32_t*)h->stat.p;
   B.static_legal = (int32_t*)h->legal.p;
   B.agent_ticks = (int64_t*)h->ticks.p;
+  B.order = (const int32_t*)h->order_d.p;
   B.n_agents = (int32_t)Na;
-  B.lds_fac = 0;
   B.prof = nullptr;
 #if defined(CSDO_PROFILE_PHASES)
   if ((rc = h->prof.ensure(Na * 48 * sizeof(int64_t))) != CSDO_OK) return rc;
@@ -166,16 +230,49 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   HIP_OK(hipEventRecord(h->ev0, s), CSDO_EDEVICE);
-  if (launch_dsqp(h->dev, h->hb.max_nt, h->hb.max_obs, h->hb.max_planes, s) != hipSuccess) return CSDO_EDEVICE;
+  const int ng = (int)h->groups.size();
+  for (int g = 0; g < ng; ++g) {   // fork: every group starts when the caller's stream reaches this point
+    hipStream_t gs = g == 0 ? s : h->side[g - 1];
+    if (g > 0) HIP_OK(hipStreamWaitEvent(gs, h->ev0, 0), CSDO_EDEVICE);
+    HIP_OK(hipEventRecord(h->g_begin[g], gs), CSDO_EDEVICE);
+    if (launch_dsqp(h->dev, h->groups[g], gs) != hipSuccess) return CSDO_EDEVICE;
+    HIP_OK(hipEventRecord(h->g_end[g], gs), CSDO_EDEVICE);
+  }
+  for (int g = 1; g < ng; ++g) HIP_OK(hipStreamWaitEvent(s, h->g_end[g], 0), CSDO_EDEVICE);   // join
   HIP_OK(hipEventRecord(h->ev1, s), CSDO_EDEVICE);
   HIP_OK(hipEventSynchronize(h->ev1), CSDO_EDEVICE);
   float ms = 0.f;
+  for (int g = 0; g < ng; ++g) {
+    HIP_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end[g]), CSDO_EDEVICE);
+    h->groups[g].seconds = (double)ms * 1e-3;
+  }
   HIP_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1), CSDO_EDEVICE);
   h->last_kernel_s = (double)ms * 1e-3;
   return CSDO_OK;
 }
 
 double csdo_dsqp_last_kernel_seconds(csdo_handle h) { return h ? h->last_kernel_s : 0.0; }
+
+int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode) {
+  if (!h || mode < 0 || mode > 2) return CSDO_EINVAL;
+  h->min_mode = mode;
+  return CSDO_OK;
+}
+
+int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t cap) {
+  if (!h || !h->uploaded || (cap > 0 && !out)) return CSDO_EINVAL;
+  const int ng = (int)h->groups.size();
+  for (int g = 0; g < ng && g < cap; ++g) {
+    const LaunchGroup& G = h->groups[g];
+    out[g].n_agents = G.count;
+    out[g].threads = G.block;
+    out[g].residency_mode = G.mode;
+    out[g].max_nt = G.max_nt;
+    out[g].lds_bytes = (int64_t)G.lds_bytes;
+    out[g].seconds = G.seconds;
+  }
+  return ng;
+}
 
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles) {
   if (!h || !h->uploaded) return nullptr;
@@ -208,7 +305,10 @@ int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
                  h->h_stat.data(), h->h_legal.data(), results);
   for (int w = 0; w < n_worlds; ++w) {
     int64_t mx = 0;
-    for (int a = hb.world_first_agent[w]; a < hb.world_first_agent[w + 1]; ++a) mx = std::max(mx, h->h_ticks[a]);
+    for (int a = hb.world_first_agent[w]; a < hb.world_first_agent[w + 1]; ++a) {
+      mx = std::max(mx, h->h_ticks[a]);
+      if (results[w].agent_seconds) results[w].agent_seconds[a - hb.world_first_agent[w]] = (double)h->h_ticks[a] * 1e-8;
+    }
     results[w].t_max_individual = (double)mx * 1e-8;  // wall_clock64 ticks at 100 MHz
     results[w].t_device = h->last_kernel_s;
   }

@@ -63,8 +63,9 @@ struct DeviceBatch {
   int32_t* last_status;
   int32_t* static_legal;   // per agent: 1 if every initial box was legal
   int64_t* agent_ticks;    // per agent device time, 100 MHz ticks
+  const int32_t* order;    // launch order: agents grouped by kernel class, heaviest first inside a group
   int32_t n_agents;
-  int32_t lds_fac;         // unused (coupling blocks are cached in solver-lane registers)
+  int32_t _pad;
   int64_t* prof;           // diagnostic builds only: [n_agents][16] shader-clock ticks per phase, else null
   SolverParams prm;
 };

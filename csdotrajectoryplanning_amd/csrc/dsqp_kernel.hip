@@ -1,5 +1,5 @@
 // dsqp_kernel.hip — gfx950 kernels of the DO backend.
-//   dsqp_agent_kernel<BLOCK>: one workgroup per agent runs the whole per-agent SQP (dsqp_program.h) start to
+//   dsqp_agent_kernel<BLOCK,BIG,SPLIT> (dsqp_kernel_body.h, one translation unit per instantiation): one workgroup per agent runs the whole per-agent SQP (dsqp_program.h) start to
 //     finish; grid = number of agents in the batch; no host round trips, no inter-workgroup communication
 //     (agents are independent once the separating planes are fixed, sqp/dsqp_solver.cc:1198-1205).
 //   box_kernel: one lane per point, safe boxes for arbitrary points (csdo_generate_boxes).
@@ -11,71 +11,8 @@
 
 namespace csdo {
 
-// BLOCK = 2 * (lanes per role): threads [0, BLOCK/2) are row lanes, [BLOCK/2, BLOCK) solver lanes (dsqp_program.h)
-// BIG: E_r and the bounds stay in the workspace and LDS holds only the 6-vectors (horizons / obstacle counts whose
-// working set exceeds 160 KB of LDS)
-// SPLIT: two specialised lanes per timestep (row waves + solver waves); otherwise one thread per timestep does both
-template <int BLOCK, bool BIG, bool SPLIT>
-__global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, const int max_obs, const int max_planes) {
-  extern __shared__ __align__(16) double lds[];
-  const int agent = (int)blockIdx.x;
-  if (agent >= B.n_agents) return;
-  const long long t_begin = wall_clock64();
-  const int ad_Nt = uniform_i32(B.agents[agent].Nt);
-  const long long ad_fac_off = uniform_i64(B.agents[agent].fac_off);
-  const long long ad_rows_off = uniform_i64(B.agents[agent].rows_off);
-  const int ad_n_planes = uniform_i32(B.agents[agent].n_planes);
-  const int st = (ad_Nt + 1) & ~1;
-  Shm sh;
-  sh.stride = st;
-  sh.vec = lds;
-  sh.pl = sh.vec + 6 * st;
-  sh.pr = sh.pl + 6 * st;
-  sh.carry = sh.pl;     // aliases, see Shm
-  sh.carry2 = sh.pr;
-  sh.lohi = sh.pr + 6 * st;
-  sh.red = sh.lohi;                       // BIG: this region is only the 12-wide reduction scratch
-  sh.sinvs = sh.lohi + 22 * st;
-  sh.er = sh.sinvs + 22 * st;
-  sh.obs = BIG ? (sh.red + 12 * st) : (sh.er + 38 * st);
-  sh.bcast = sh.obs + 3 * max_obs;
-  sh.tvec = sh.bcast + 32;
-  sh.tinv = sh.tvec + 2 * TAIL_N;
-  sh.pc = BIG ? (B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes) : (sh.tinv + TAIL_N * 38);
-  (void)max_planes;
-  double* fac_global = B.fac_ws + ad_fac_off;
-  sh.facE = fac_global;
-  sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;
-  sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
-  ProgramOut po;
-  if constexpr (!SPLIT) {
-    RowRegs lr;
-    SolvRegs ls;
-    agent_program<ROLE_BOTH, BIG>(B, agent, sh, lr, ls, po);
-    if (threadIdx.x == 0) {
-      B.sqp_iters[agent] = po.sqp_iters;
-      B.admm_iters[agent] = po.admm_iters;
-      B.last_status[agent] = po.last_status;
-      B.static_legal[agent] = po.static_legal;
-      B.agent_ticks[agent] = wall_clock64() - t_begin;
-    }
-  } else if (threadIdx.x < BLOCK / 2) {        // row waves
-    RowRegs lr;
-    SolvRegs ls_unused;
-    agent_program<ROLE_ROW, BIG>(B, agent, sh, lr, ls_unused, po);
-    if (threadIdx.x == 0) {
-      B.sqp_iters[agent] = po.sqp_iters;
-      B.admm_iters[agent] = po.admm_iters;
-      B.last_status[agent] = po.last_status;
-      B.static_legal[agent] = po.static_legal;
-      B.agent_ticks[agent] = wall_clock64() - t_begin;
-    }
-  } else {                              // solver waves
-    RowRegs lr_unused;
-    SolvRegs ls;
-    agent_program<ROLE_SOLVER, BIG>(B, agent, sh, lr_unused, ls, po);
-  }
-}
+template <int BLOCK, int MODE, bool SPLIT>
+hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, hipStream_t stream);   // dsqp_variant.hip
 
 __global__ void box_kernel(const double* __restrict__ pts, int n, const double* __restrict__ obs_aos, int n_obs,
                            double dimx, double dimy, double rv, double* __restrict__ boxes,
@@ -97,36 +34,38 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
   boxes[4 * i + 3] = b.y_max;
 }
 
-size_t dsqp_lds_bytes(int max_nt, int max_obs, int max_planes, bool big) {
-  const int st = (max_nt + 1) & ~1;
-  const size_t per_lane = big ? 30 : 100;  // vec 6 + pl 6 + pr 6 + (red 12 | lohi 22 + sinv 22 + er 38)
-  return (per_lane * st + (size_t)3 * max_obs + 32 + 2 * TAIL_N + TAIL_N * 38 + (big ? 0 : (size_t)3 * max_planes)) *
+size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode) {
+  const int st = (nt + 1) & ~1;
+  // vec 6 + pl 6 + pr 6 + (mode 0: bounds 22 + pivot inverses 22 + E_r 38 | mode 1: E_r 38 | mode 2: reduction scratch 12)
+  const size_t per_lane = mode == 0 ? 100 : (mode == 1 ? 56 : 30);
+  return (per_lane * st + (size_t)3 * n_obs + 32 + 2 * TAIL_N + TAIL_N * 38 + (mode == 2 ? 0 : (size_t)3 * n_planes)) *
          sizeof(double);
 }
 
-hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, int max_planes, hipStream_t stream) {
-  constexpr size_t LDS_CAP = 160 * 1024;
-  DeviceBatch b = B;
-  const bool big = max_nt > 256 || dsqp_lds_bytes(max_nt, max_obs, max_planes, false) > LDS_CAP;   // non-BIG fits up to Nt ~ 200
-  b.lds_fac = big ? 0 : 1;
-  const size_t bytes = dsqp_lds_bytes(max_nt, max_obs, max_planes, big);
-  if (bytes > LDS_CAP) return hipErrorInvalidValue;
-  auto go = [&](auto kernel, int block) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(b.n_agents), dim3(block), bytes, stream, b, max_obs, max_planes);
-    return hipGetLastError();
-  };
-  // Default: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024 threads with
-  // 128 registers per lane: correct but spills; horizons that long are outside the benchmark sets).
-  // CSDO_SINGLE_ROLE=1 selects one thread per timestep playing both roles (256 threads, 512 registers per lane) for
-  // Nt <= 256: measured 10 % slower (no overlap of the inter-vehicle pass with the row update); kept for comparison.
-  static const bool single = [] { const char* e = getenv("CSDO_SINGLE_ROLE"); return e && e[0] == '1'; }();
-  if (max_nt <= 256 && single)
-    return big ? go(dsqp_agent_kernel<256, true, false>, 256) : go(dsqp_agent_kernel<256, false, false>, 256);
-  if (max_nt <= 128) return big ? go(dsqp_agent_kernel<256, true, true>, 256) : go(dsqp_agent_kernel<256, false, true>, 256);
-  if (max_nt <= 256) return big ? go(dsqp_agent_kernel<512, true, true>, 512) : go(dsqp_agent_kernel<512, false, true>, 512);
-  return go(dsqp_agent_kernel<1024, true, true>, 1024);
+constexpr size_t LDS_CAP = 160 * 1024;
+
+int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode) {
+  // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024
+  // threads with 128 registers per lane: correct but spills; horizons that long are outside the benchmark sets)
+  const int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : 1024);
+  *mode = 2;
+  if (block == 512 && dsqp_lds_bytes(nt, n_obs, n_planes, 1) <= LDS_CAP) *mode = 1;
+  if (block <= 512 && dsqp_lds_bytes(nt, n_obs, n_planes, 0) <= LDS_CAP) *mode = 0;
+  return block;
+}
+
+hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, hipStream_t stream) {
+  if (g.count <= 0) return hipSuccess;
+  if (g.lds_bytes > LDS_CAP) return hipErrorInvalidValue;
+  switch (g.block * 10 + g.mode) {
+    case 2560: return launch_variant<256, 0, true>(B, g, stream);
+    case 2562: return launch_variant<256, 2, true>(B, g, stream);
+    case 5120: return launch_variant<512, 0, true>(B, g, stream);
+    case 5121: return launch_variant<512, 1, true>(B, g, stream);
+    case 5122: return launch_variant<512, 2, true>(B, g, stream);
+    case 10242: return launch_variant<1024, 2, true>(B, g, stream);
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,

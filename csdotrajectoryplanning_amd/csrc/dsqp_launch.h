@@ -5,8 +5,20 @@
 #include "csdo_device_types.h"
 
 namespace csdo {
-size_t dsqp_lds_bytes(int max_nt, int max_obs, int max_planes, bool big);
-hipError_t launch_dsqp(const DeviceBatch& B, int max_nt, int max_obs, int max_planes, hipStream_t stream);
+// One launch = one group of agents that share a kernel instantiation: workgroup size by horizon and LDS residency
+// mode by working set (agent_program in dsqp_program.h: 0 everything in LDS ... 2 only the 6-vectors).
+struct LaunchGroup {
+  int first = 0, count = 0;   // range in DeviceBatch::order
+  int block = 0;              // threads per workgroup: 256 (Nt <= 128), 512 (<= 256), 1024 (<= 512)
+  int mode = 0;
+  int max_nt = 0;
+  size_t lds_bytes = 0;       // dynamic LDS of the launch: the largest working set among the group's agents
+  double seconds = 0.0;       // duration of the last launch (HIP events on the group's stream)
+};
+size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode);   // LDS working set of one agent
+// kernel class of one agent: returns the workgroup size and sets the residency mode
+int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode);
+hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, hipStream_t stream);
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,
                         double* boxes, int* status, hipStream_t stream);
 }  // namespace csdo

@@ -223,7 +223,7 @@ struct Shm {
   double* bcast;    // [32] block-wide results
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
   double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
-  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in BIG mode)
+  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in MODE 2)
   int stride;
 };
 
@@ -238,7 +238,7 @@ struct AgentCtx {
 };
 
 // inter-vehicle row workspace: SoA by field, [field][4K] per agent (the 4 rows of a plane are contiguous)
-enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };   // then [3K] plane shares (BIG)
+enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };   // then [3K] plane shares (MODE 2)
 
 // =========================================================================================================
 // Block-wide reductions.  Partials are stored per lane in sh.pl/sh.pr (12 slots); after a barrier the first wave
@@ -366,12 +366,60 @@ CSDO_FN bool box_valid(const BoxD& b, const double* obs, int n_obs, double dimx,
   return !hit;
 }
 
-// generateLocalBox, corridor.cc:278-324: grow by 0.1 in the order +y, -x, -y, +x until blocked or >= 10 m
+// The culled obstacles of one seed point held in registers (first OBS_NEAR of them; any further ones stay in the
+// mask).  Unused slots hold an obstacle at x = +inf, which fails `ox < x_max + infl` for every box.
+constexpr int OBS_NEAR = 8;
+struct ObsNear {
+  double ox[OBS_NEAR], oy[OBS_NEAR], infl[OBS_NEAR];
+  ObsMask rest;
+  bool has_rest;
+};
+
+CSDO_FN ObsNear load_near(const ObsMask& M, const double* obs, int n_obs, double rv) {
+  ObsNear R;
+  ObsMask m = M;
+  CSDO_FOR(j, OBS_NEAR, {
+    int k = -1;
+    if (m.m[0]) {
+      k = ctz64(m.m[0]);
+      m.m[0] &= m.m[0] - 1;
+    } else if (m.m[1]) {
+      k = 64 + ctz64(m.m[1]);
+      m.m[1] &= m.m[1] - 1;
+    } else if (m.m[2]) {
+      k = 128 + ctz64(m.m[2]);
+      m.m[2] &= m.m[2] - 1;
+    } else if (m.m[3]) {
+      k = 192 + ctz64(m.m[3]);
+      m.m[3] &= m.m[3] - 1;
+    }
+    R.ox[j] = (k >= 0) ? obs[k] : INFINITY;
+    R.oy[j] = (k >= 0) ? obs[n_obs + k] : 0.0;
+    R.infl[j] = (k >= 0) ? (obs[2 * n_obs + k] + rv) : 0.0;
+  });
+  R.rest = m;
+  R.has_rest = (m.m[0] | m.m[1] | m.m[2] | m.m[3]) != 0ull || n_obs > OBS_MASK_CAP;
+  return R;
+}
+
+// generateLocalBox, corridor.cc:278-324: grow by 0.1 in the order +y, -x, -y, +x until blocked or >= 10 m.
+// isBoxValid's obstacle test is the conjunction of four strict inequalities, one per box side; a trial step moves one
+// side, so only that side's inequality is re-evaluated (one bit per register-held obstacle) and and-ed with the
+// cached bits of the other three sides: same booleans as testing the whole trial box against every obstacle.
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
                       BoxD& res) {
   const double ds = 0.1, l_limit = 10.0;
   const ObsMask M = cull_obstacles(xc, yc, obs, n_obs, rv);
+  const ObsNear R = load_near(M, obs, n_obs, rv);
   BoxD box{xc, yc, xc, yc};
+  // side bits of the current box: bit j set <=> obstacle j satisfies that side's inequality
+  unsigned s_ymax = 0, s_xmin = 0, s_ymin = 0, s_xmax = 0;
+  CSDO_FOR(j, OBS_NEAR, {
+    s_ymax |= (R.oy[j] < (box.y_max + R.infl[j])) ? (1u << j) : 0u;
+    s_xmin |= ((box.x_min - R.infl[j]) < R.ox[j]) ? (1u << j) : 0u;
+    s_ymin |= ((box.y_min - R.infl[j]) < R.oy[j]) ? (1u << j) : 0u;
+    s_xmax |= (R.ox[j] < (box.x_max + R.infl[j])) ? (1u << j) : 0u;
+  });
   double len[4] = {0, 0, 0, 0};
   bool on[4] = {true, true, true, true};
   int num_expand = 0;
@@ -379,14 +427,50 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
     CSDO_FOR(d, 4, {
       if (on[d]) {
         BoxD tr = box;
-        if constexpr (d == 0) tr.y_max += ds;
-        if constexpr (d == 1) tr.x_min -= ds;
-        if constexpr (d == 2) tr.y_min -= ds;
-        if constexpr (d == 3) tr.x_max += ds;
-        if (box_valid(tr, obs, n_obs, dimx, dimy, rv, M)) {
+        unsigned t_ymax = s_ymax, t_xmin = s_xmin, t_ymin = s_ymin, t_xmax = s_xmax;
+        if constexpr (d == 0) {
+          tr.y_max += ds;
+          t_ymax = 0;
+          CSDO_FOR(j, OBS_NEAR, { t_ymax |= (R.oy[j] < (tr.y_max + R.infl[j])) ? (1u << j) : 0u; });
+        }
+        if constexpr (d == 1) {
+          tr.x_min -= ds;
+          t_xmin = 0;
+          CSDO_FOR(j, OBS_NEAR, { t_xmin |= ((tr.x_min - R.infl[j]) < R.ox[j]) ? (1u << j) : 0u; });
+        }
+        if constexpr (d == 2) {
+          tr.y_min -= ds;
+          t_ymin = 0;
+          CSDO_FOR(j, OBS_NEAR, { t_ymin |= ((tr.y_min - R.infl[j]) < R.oy[j]) ? (1u << j) : 0u; });
+        }
+        if constexpr (d == 3) {
+          tr.x_max += ds;
+          t_xmax = 0;
+          CSDO_FOR(j, OBS_NEAR, { t_xmax |= (R.ox[j] < (tr.x_max + R.infl[j])) ? (1u << j) : 0u; });
+        }
+        bool ok = !(tr.x_min < rv || tr.x_max > dimx - rv || tr.y_min < rv || tr.y_max > dimy - rv) &&
+                  (t_ymax & t_xmin & t_ymin & t_xmax) == 0u;
+        if (ok && R.has_rest) {   // more than OBS_NEAR obstacles near this seed: the others the slow way
+          bool hit = false;
+          CSDO_FOR(w, 4, {
+            unsigned long long m = R.rest.m[w];
+            while (m && !hit) {
+              const int k = 64 * w + ctz64(m);
+              m &= m - 1;
+              hit = obstacle_in_box(tr, obs, n_obs, k, rv);
+            }
+          });
+          for (int k = OBS_MASK_CAP; k < n_obs && !hit; ++k) hit = obstacle_in_box(tr, obs, n_obs, k, rv);
+          ok = !hit;
+        }
+        if (ok) {
           num_expand++;
           len[d] += ds;
           box = tr;
+          s_ymax = t_ymax;
+          s_xmin = t_xmin;
+          s_ymin = t_ymin;
+          s_xmax = t_xmax;
           if (len[d] >= l_limit) on[d] = false;
         } else {
           on[d] = false;
@@ -543,8 +627,11 @@ CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
   else return (S.eqmask & (1u << I)) ? rho_eq : rho;
 }
 
-// BIG: horizons whose E_r blocks and bounds do not fit in LDS (Nt > 256) read them from the workspace instead.
-template <int ROLE, bool BIG, class RowStore, class SolvStore>
+// MODE: what an ADMM block keeps in LDS beside the 6-vectors, chosen per agent by its working set (dsqp_kernel.hip):
+//   0  coupling blocks E_r, pivot inverses, bounds and per-plane rhs shares      (100 doubles per timestep)
+//   1  E_r and the plane shares; pivot inverses and bounds are read from the L2-resident workspace   (56)
+//   2  only the 6-vectors and the reduction scratch: horizons beyond 256                             (30)
+template <int ROLE, int MODE, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out);
 

@@ -10,8 +10,8 @@ namespace csdo {
 // factor-time exchange lives in global memory, coalesced [k][stride]
 #define SX(k, t) sh.facX[(k) * sh.stride + (t)]
 // E_r of node t: LDS copy, or the workspace copy for long horizons
-#define ER(k, t) (BIG ? SH(facE, 36 + (k), t) : SH(er, k, t))
-#define SINV(k, t) (BIG ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
+#define ER(k, t) (MODE == 2 ? SH(facE, 36 + (k), t) : SH(er, k, t))
+#define SINV(k, t) (MODE != 0 ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
 #define CD(slot, t) sh.cold[(slot) * sh.stride + (t)]
 #define WS(slot, t) sh.cold[(slot) * sh.stride + (t)]
 
@@ -108,7 +108,7 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 }
 
 // =========================================================================================================
-template <int ROLE, bool BIG, class RowStore, class SolvStore>
+template <int ROLE, int MODE, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out) {
   AgentDesc ad = B.agents[agent];
@@ -1074,7 +1074,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             if constexpr (row_col(i, s) >= 0) S.c[i][s] = WS(W_C + 3 * i + s, t);
           });
           // bounds are read once per iteration: LDS, not registers (layout: Shm::lohi)
-          if constexpr (!BIG) {
+          if constexpr (MODE == 0) {
             if constexpr (i < 7) SH(lohi, i, t) = WS(W_LO + i, t);
             if constexpr (i >= 7 && i < 13) {
               SH(lohi, i, t) = WS(W_LO + i, t);
@@ -1094,10 +1094,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_SLANES(t) {  // load the solver-lane cache and the inter-row share of the first rhs
         SolvRegs& V = CSDO_SS(t);
-        if constexpr (!BIG) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
+        if constexpr (MODE == 0) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
         CSDO_FOR(k, 36, {
           V.el[k] = SH(facE, k, t);
-          if constexpr (!BIG) SH(er, k, t) = SH(facE, 36 + k, t);
+          if constexpr (MODE != 2) SH(er, k, t) = SH(facE, 36 + k, t);
         });
         plane_pass(std::false_type{}, std::false_type{}, t, rho);
       }
@@ -1158,7 +1158,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               const double rinv = rho_row<i>(S, rinv_in, rinv_eq);   // = 1.0 / rh (rho_inv_vec of OSQP)
               const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
               double lo_i, hi_i;
-              if constexpr (BIG) {
+              if constexpr (MODE != 0) {
                 lo_i = WS(W_LO + i, t);
                 hi_i = WS(W_HI + i, t);
               } else {

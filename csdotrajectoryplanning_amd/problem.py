@@ -69,6 +69,7 @@ class Solution:
     t_total: float = 0.0
     t_device: float = 0.0
     t_max_individual: float = 0.0
+    agent_seconds: np.ndarray = None   # [Na] per-agent solve time
     _c: abi.Result = field(default=None, repr=False)
 
     @staticmethod
@@ -81,6 +82,8 @@ class Solution:
         r.sqp_iters = abi.as_int32_p(s.sqp_iters)
         r.admm_iters = abi.as_int32_p(s.admm_iters)
         r.last_status = abi.as_int32_p(s.last_status)
+        s.agent_seconds = np.zeros(Na)
+        r.agent_seconds = abi.as_double_p(s.agent_seconds)
         s._c = r
         return s
 

@@ -57,6 +57,17 @@ class DsqpHandle:
         check(lib().csdo_dsqp_run(self._h, C.c_void_p(stream) if stream else None), "csdo_dsqp_run")
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
 
+    def set_min_residency_mode(self, mode):
+        check(lib().csdo_dsqp_set_min_residency_mode(self._h, int(mode)), "csdo_dsqp_set_min_residency_mode")
+
+    def launch_groups(self):
+        """How the uploaded batch is launched (csdo_dsqp_launch_groups): a list of dicts, one per concurrent kernel."""
+        buf = (abi.LaunchGroup * 8)()
+        n = lib().csdo_dsqp_launch_groups(self._h, buf, 8)
+        if n < 0:
+            check(n, "csdo_dsqp_launch_groups")
+        return [{f: getattr(buf[i], f) for f, _ in abi.LaunchGroup._fields_} for i in range(min(n, 8))]
+
     def download(self):
         worlds = self._keep
         sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]

@@ -101,6 +101,8 @@ typedef struct csdo_result {
   double t_total;              /* seconds, host wall clock of the call (H2D + kernels + D2H) */
   double t_device;             /* seconds, device time of the solve kernels (HIP events) */
   double t_max_individual;     /* getMaxOfRuntimes(): slowest agent's device time */
+  double* agent_seconds;       /* [Na] or NULL: per-agent solve time (the reference's SolutionStatistics runtimes,
+                                  sqp/dsqp_solver.cc:1206-1219); device wall clock of the agent's workgroup */
 } csdo_result;
 
 typedef struct csdo_handle_s* csdo_handle;
@@ -122,6 +124,23 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream /* hipStream_t or NULL for the
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
 /* Device time of the last csdo_dsqp_run in seconds (HIP events on the launch stream) and the kernel's own name. */
 double csdo_dsqp_last_kernel_seconds(csdo_handle h);
+/* How the uploaded batch is launched: agents are grouped by kernel class (workgroup size by horizon; LDS residency by
+ * working set: 0 = coupling blocks, pivot inverses and bounds all in LDS, 1 = pivot inverses and bounds read from the
+ * L2-resident workspace, 2 = only the exchange vectors in LDS) and the groups run concurrently.  Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
+ * the duration of the group's kernel in the last csdo_dsqp_run.  No reference counterpart (the reference loops over
+ * agents serially, sqp/dsqp_solver.cc:1198-1205). */
+typedef struct csdo_launch_group {
+  int32_t n_agents;
+  int32_t threads;             /* per workgroup: 256, 512 or 1024 */
+  int32_t residency_mode;      /* 0, 1 or 2, see above */
+  int32_t max_nt;
+  int64_t lds_bytes;
+  double seconds;
+} csdo_launch_group;
+int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t cap);
+/* Testing / tuning knob: from the next upload on, no agent uses a residency mode below `mode` (0 restores the
+ * automatic choice).  Results do not depend on the mode, only the speed does. */
+int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
 /* Device pointer to the packed solutions of the last run ([sum Na][Nt_stride][6] doubles) for collectives. */
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles);
 

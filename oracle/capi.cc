@@ -96,6 +96,8 @@ int csdo_oracle_solve(const csdo_problem* in, csdo_result* out, int n_threads) {
   out->t_total = R.t_total;
   out->t_device = 0.0;
   out->t_max_individual = R.t_max_individual;
+  if (out->agent_seconds)
+    for (size_t a = 0; a < R.agent_seconds.size(); ++a) out->agent_seconds[a] = R.agent_seconds[a];
   return CSDO_OK;
 }
 

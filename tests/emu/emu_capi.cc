@@ -11,7 +11,9 @@
 
 using namespace csdo;
 
-extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results) {
+// mode: LDS residency of the ADMM blocks (agent_program in dsqp_program.h); all three give identical results
+extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode) {
+  if (mode < 0 || mode > 2) return CSDO_EINVAL;
   HostBatch hb;
   const int rc = pack_worlds(worlds, n_worlds, hb);
   if (rc != CSDO_OK) return rc;
@@ -38,7 +40,7 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
   B.static_legal = legal.data();
   B.agent_ticks = ticks.data();
   B.n_agents = Na;
-  B.lds_fac = 0;
+  B.order = nullptr;
   B.prm = hb.prm;
   for (int a = 0; a < Na; ++a) {
     const AgentDesc& ad = hb.agents[a];
@@ -60,13 +62,26 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
     sh.tvec = sh.bcast + 32;
     sh.tinv = sh.tvec + 2 * TAIL_N;
     sh.pc = sh.tinv + TAIL_N * 38;
+    std::vector<double> pc_ws;
+    if (mode == 1) {            // as dsqp_kernel_body.h: no bounds / pivot inverses in LDS, reductions over the E_r region
+      sh.lohi = sh.sinvs = nullptr;
+      sh.red = sh.er;
+    } else if (mode == 2) {     // only the 6-vectors and the reduction scratch
+      sh.sinvs = sh.er = nullptr;
+      sh.red = sh.lohi;
+      sh.lohi = nullptr;
+      pc_ws.assign((size_t)3 * hb.max_planes + 1, 0.0);
+      sh.pc = pc_ws.data();
+    }
     sh.facE = fac_ws.data() + ad.fac_off;
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;
     sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
     std::vector<RowRegs> lanes_r(ad.Nt);
     std::vector<SolvRegs> lanes_s(std::max<int>(ad.Nt, TAIL_N));
     ProgramOut po{};
-    agent_program<ROLE_BOTH, false>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    if (mode == 0) agent_program<ROLE_BOTH, 0>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else if (mode == 1) agent_program<ROLE_BOTH, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else agent_program<ROLE_BOTH, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     sqp[a] = po.sqp_iters;
     admm[a] = po.admm_iters;
     stat[a] = po.last_status;
@@ -76,6 +91,10 @@ extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds
                  results);
   for (int w = 0; w < n_worlds; ++w) results[w].t_total = results[w].t_device = results[w].t_max_individual = 0.0;
   return CSDO_OK;
+}
+
+extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results) {
+  return csdo_emu_solve_batch_mode(worlds, n_worlds, results, 0);
 }
 
 extern "C" int csdo_emu_generate_boxes(const double* pts, int32_t n, const double* obstacles, int32_t n_obs,

@@ -22,16 +22,17 @@ def lib():
         build()
         _LIB = C.CDLL(os.path.join(_ROOT, "tests", "emu", "libcsdo_emu.so"))
         _LIB.csdo_emu_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result)]
+        _LIB.csdo_emu_solve_batch_mode.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
         _LIB.csdo_emu_generate_boxes.argtypes = [abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                                  C.c_double, C.POINTER(abi.Vehicle), abi.c_double_p, abi.c_int32_p]
     return _LIB
 
 
-def solve_batch(worlds):
+def solve_batch(worlds, mode=0):
     sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
     probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
     res = (abi.Result * len(worlds))(*[s._c for s in sols])
-    rc = lib().csdo_emu_solve_batch(probs, len(worlds), res)
+    rc = lib().csdo_emu_solve_batch_mode(probs, len(worlds), res, mode)
     assert rc == 0, rc
     for s, r in zip(sols, res):
         s._c = r
@@ -39,8 +40,8 @@ def solve_batch(worlds):
     return sols
 
 
-def solve(world: World) -> Solution:
-    return solve_batch([world])[0]
+def solve(world: World, mode=0) -> Solution:
+    return solve_batch([world], mode)[0]
 
 
 def generate_boxes(points, obstacles, dimx, dimy, veh):

@@ -84,6 +84,26 @@ def test_gpu_is_deterministic_and_handle_is_reusable(gpu_handle, veh_parm):
     assert np.array_equal(a.solutions, b.solutions) and np.array_equal(a.corridors, b.corridors)
 
 
+def test_gpu_lds_residency_modes_are_bit_identical(gpu_handle, veh_parm):
+    """Agents whose working set exceeds LDS read pivot inverses / bounds (mode 1) or also the coupling blocks (mode 2)
+    from the workspace: same doubles, same arithmetic, so bit-identical results; mixed batches launch concurrently."""
+    veh, parm = veh_parm
+    w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    w2, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)      # Nt = 169: 512-thread class
+    ref = gpu_handle.solve_batch([w1, w2])
+    try:
+        for mode in (1, 2):
+            gpu_handle.set_min_residency_mode(mode)
+            got = gpu_handle.solve_batch([w1, w2])
+            groups = gpu_handle.launch_groups()
+            assert all(g["residency_mode"] >= mode for g in groups) and sum(g["n_agents"] for g in groups) == w1.Na + w2.Na
+            for r, g in zip(ref, got):
+                assert np.array_equal(r.solutions, g.solutions) and np.array_equal(r.corridors, g.corridors)
+                assert np.array_equal(r.admm_iters, g.admm_iters) and np.array_equal(r.last_status, g.last_status)
+    finally:
+        gpu_handle.set_min_residency_mode(0)
+
+
 def test_gpu_batch_equals_separate_solves(gpu_handle, veh_parm):
     veh, parm = veh_parm
     w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)

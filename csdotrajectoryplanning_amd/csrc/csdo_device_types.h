@@ -72,7 +72,7 @@ struct DeviceBatch {
 
 constexpr int ROWS_WS_STRIDE = 9;   // doubles per inter row in rows_ws: 8 fields + room for the per-plane rhs shares
 constexpr int FAC_E_DOUBLES = 72;   // E_l + E_r per node, lane-major
-constexpr int FAC_X_DOUBLES = 78;   // factor-time exchange per node: U_l(21) + U_r(21) + Rnew(36)
+constexpr int FAC_X_DOUBLES = 100;  // factor-time exchange per node: U_l(21) + U_r(21) + Rnew(36) + diagonal block (21, padded)
 constexpr int COLD_DOUBLES = 210;   // per-lane workspace slots (WsSlot in dsqp_program.h)
 
 }  // namespace csdo

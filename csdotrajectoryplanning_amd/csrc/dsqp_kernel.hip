@@ -36,8 +36,8 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
 
 size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode) {
   const int st = (nt + 1) & ~1;
-  // vec 6 + pl 6 + pr 6 + (mode 0: bounds 22 + pivot inverses 22 + E_r 38 | mode 1: E_r 38 | mode 2: reduction scratch 12)
-  const size_t per_lane = mode == 0 ? 100 : (mode == 1 ? 56 : 30);
+  // vec 6 + pr 6 + (mode 0: bounds 22 + pivot inverses 22 + E_r 38 | mode 1: E_r 38 | mode 2: hand-over 6 + reduction scratch 12)
+  const size_t per_lane = mode == 0 ? 94 : (mode == 1 ? 50 : 30);
   return (per_lane * st + (size_t)3 * n_obs + 32 + 2 * TAIL_N + TAIL_N * 38 + (mode == 2 ? 0 : (size_t)3 * n_planes)) *
          sizeof(double);
 }

@@ -26,25 +26,27 @@ __global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, 
   Shm sh;
   sh.stride = st;
   sh.vec = lds;
-  sh.pl = sh.vec + 6 * st;
-  sh.pr = sh.pl + 6 * st;
-  sh.carry = sh.pl;     // aliases, see Shm
-  sh.carry2 = sh.pr;
+  sh.pl = sh.vec;       // aliases, see Shm
+  sh.pr = sh.vec + 6 * st;
+  sh.carry = sh.pr;
   double* rest = sh.pr + 6 * st;
   if constexpr (MODE == 0) {
     sh.lohi = rest;
-    sh.red = sh.lohi;                     // reductions only run between ADMM blocks (see Shm)
+    sh.red = sh.lohi;                     // reductions only run between ADMM blocks
     sh.sinvs = sh.lohi + 22 * st;
     sh.er = sh.sinvs + 22 * st;
+    sh.carry2 = sh.er;
     rest = sh.er + 38 * st;
   } else if constexpr (MODE == 1) {
     sh.lohi = sh.sinvs = nullptr;
     sh.er = rest;
     sh.red = sh.er;
+    sh.carry2 = sh.er + 12 * st;
     rest = sh.er + 38 * st;
   } else {
     sh.lohi = sh.sinvs = sh.er = nullptr;
-    sh.red = rest;
+    sh.carry2 = rest;
+    sh.red = sh.carry2 + 6 * st;
     rest = sh.red + 12 * st;
   }
   sh.obs = rest;

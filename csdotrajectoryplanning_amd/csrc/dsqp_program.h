@@ -32,6 +32,7 @@
 #if defined(CSDO_LANE_MODE_DEVICE)
 #include <hip/hip_runtime.h>
 #define CSDO_FN __device__ __forceinline__
+#define CSDO_NOINLINE __device__ __noinline__
 // Two specialised lanes per timestep: row lanes are threads [0, Nt), solver lanes are threads [HALF, HALF + Nt).
 // The program is instantiated once per role (ROLE_ROW for the first half of the workgroup, ROLE_SOLVER for the
 // second): blocks of the other role are compiled out, so each instantiation only carries its own register state.
@@ -45,6 +46,11 @@
 // tail lanes: solver threads [base, base + n_tail), independent of Nt (n_tail <= 36)
 #define CSDO_TLANES(t) \
   if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
+// every thread of the solver half, whatever Nt (element-parallel work: t in [0, nthr))
+#define CSDO_STHREADS(t, nthr)                                                              \
+  if constexpr (ROLE != ROLE_ROW)                                                           \
+    if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
+      if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0)
 #define CSDO_LS(t) lanes_r
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
@@ -67,9 +73,12 @@
 #endif
 #elif defined(CSDO_LANE_MODE_SERIAL)
 #define CSDO_FN inline
+#define CSDO_NOINLINE inline
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)
 #define CSDO_SLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < Nt; ++t)
 #define CSDO_TLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < n_tail; ++t)
+#define CSDO_STHREADS(t, nthr) \
+  if constexpr (ROLE != ROLE_ROW) if (const int nthr = 64; true) for (int t = 0; t < nthr; ++t)
 #define CSDO_LS(t) lanes_r[t]
 #define CSDO_SS(t) lanes_s[t]
 #define CSDO_SYNC() ((void)0)
@@ -133,7 +142,19 @@ CSDO_FN double uniform_f64(double v) {
   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+template <class T>
+CSDO_FN T* uniform_ptr(T* p) { return (T*)uniform_i64((long long)p); }
+// An LDS pointer that went through a function argument has lost its address space (flat accesses); rebuild it from the
+// workgroup's dynamic LDS symbol so that the compiler emits ds_* instructions again.
+CSDO_FN double* lds_ptr(double* p) {
+  extern __shared__ __align__(16) double csdo_lds_base[];
+  const int off = uniform_i32((int)(p - (double*)csdo_lds_base));
+  return csdo_lds_base + off;
+}
 #else
+CSDO_FN double* lds_ptr(double* p) { return p; }
+template <class T>
+CSDO_FN T* uniform_ptr(T* p) { return p; }
 CSDO_FN int uniform_i32(int v) { return v; }
 CSDO_FN long long uniform_i64(long long v) { return v; }
 CSDO_FN double uniform_f64(double v) { return v; }
@@ -170,11 +191,8 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   int ncols;                // 6, or 4 at t = Nt-1
 };
 struct SolvRegs {           // solver lane of timestep t: BCR node t and the inter-vehicle rows at t
-  double sinv[21];          // factor-time only: inverse of this node's pivot block (the solve reads it from LDS)
   double b[6];              // rhs -> BCR work vector -> x_tilde
   double el[36];            // coupling block to the left neighbour at this node's elimination level (E_r: LDS)
-  double fa[21], fr[36];    // factor-time only: current diagonal block and coupling to the right neighbour
-  double trow[TAIL_N];      // factor-time only: this tail lane's row during the Gauss-Jordan inversion
 };
 typedef RowRegs LaneState;  // the row lane is the "home" of a timestep
 
@@ -202,23 +220,24 @@ enum WsSlot {
 };
 
 // lane-major leading dimensions (doubles per lane) of the LDS arrays
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_facE = 72, LD_red = 12, LD_lohi = 22, LD_er = 38, LD_sinvs = 22, LD_tinv = 38;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 12, LD_lohi = 22, LD_er = 38, LD_sinvs = 22, LD_tinv = 38;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
   double* vec;      // [stride][6]  rhs / x_tilde / x exchange
-  double* pl;       // [stride][6]  BCR partials for the left neighbour   (solve only)
+  double* pl;       // [stride][6]  BCR partials for the left neighbour (forward sweep only); ALIASES vec: a node's rhs is
+                    //              in registers before it publishes its partial, and its x is written in the backward sweep
   double* pr;       // [stride][6]  BCR partials for the right neighbour  (solve only)
-  double* carry;    // [stride][6]  t -> t+1 hand-over; ALIASES pl (dead during the solve)
-  double* carry2;   // [stride][6]  t -> t-1 hand-over and inter-row rhs share; ALIASES pr
+  double* carry;    // [stride][6]  t -> t+1 hand-over; ALIASES pr (dead outside the solve)
+  double* carry2;   // [stride][6]  t -> t-1 hand-over of update_info; ALIASES E_r (only used between ADMM blocks)
   double* lohi;     // [stride][22] bounds of the home rows during an ADMM block: 0..6 eq rows (lo = hi),
                     //              7..12 lo and 13..18 hi of corridor/trust rows, 19..21 hi of the +-boxes (lo = -hi)
   double* red;      // [stride][12] reduction scratch; ALIASES lohi (reductions only run between ADMM blocks)
   double* sinvs;    // [stride][22] pivot-block inverses (packed lower) of the BCR nodes during an ADMM block
   double* er;       // [stride][38] coupling block E_r of each BCR node (E_l sits in solver-lane registers)
   double* obs;      // [3][n_obs]
-  double* facE;     // [stride][72] coupling blocks E_l (36) + E_r (36), lane-major (global; cached in solver registers)
-  double* facX;     // [78][stride] factor-time exchange (global, coalesced)
+  double* facE;     // [stride][72] coupling blocks E_l (36) + E_r (36) of every node, lane-major (global; cached in solver registers / LDS during a block)
+  double* facX;     // [100][stride] factor-time exchange and the nodes' diagonal blocks (global, coalesced)
   double* cold;     // [C_TOTAL][stride] per-agent workspace (global)
   double* bcast;    // [32] block-wide results
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
@@ -628,8 +647,8 @@ CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
 }
 
 // MODE: what an ADMM block keeps in LDS beside the 6-vectors, chosen per agent by its working set (dsqp_kernel.hip):
-//   0  coupling blocks E_r, pivot inverses, bounds and per-plane rhs shares      (100 doubles per timestep)
-//   1  E_r and the plane shares; pivot inverses and bounds are read from the L2-resident workspace   (56)
+//   0  coupling blocks E_r, pivot inverses, bounds and per-plane rhs shares      (94 doubles per timestep)
+//   1  E_r and the plane shares; pivot inverses and bounds are read from the L2-resident workspace   (50)
 //   2  only the 6-vectors and the reduction scratch: horizons beyond 256                             (30)
 template <int ROLE, int MODE, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,

@@ -9,8 +9,9 @@ namespace csdo {
 #define SH(arr, k, t) sh.arr[(t) * LD_##arr + (k)]
 // factor-time exchange lives in global memory, coalesced [k][stride]
 #define SX(k, t) sh.facX[(k) * sh.stride + (t)]
+#define FE(k, t) sh.facE[(t) * 72 + (k)]   // lane-major: one address register + immediate offsets (SoA measured slower)
 // E_r of node t: LDS copy, or the workspace copy for long horizons
-#define ER(k, t) (MODE == 2 ? SH(facE, 36 + (k), t) : SH(er, k, t))
+#define ER(k, t) (MODE == 2 ? FE(36 + (k), t) : SH(er, k, t))
 #define SINV(k, t) (MODE != 0 ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
 #define CD(slot, t) sh.cold[(slot) * sh.stride + (t)]
 #define WS(slot, t) sh.cold[(slot) * sh.stride + (t)]
@@ -108,6 +109,229 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 }
 
 // =========================================================================================================
+// BCR factorisation of H = P + sigma I + A' R A, on the solver lanes.
+// The diagonal block A_t (packed lower, 21) and the coupling R_t to the node's current right neighbour (36, rows: right
+// node's variables, columns: own) live in the workspace between levels (FA coalesced, FR = the node's E_r slot); an
+// eliminated node works through its products one at a time so that at most three 6x6 operands are
+// live.  The dense tail is inverted in LDS, element-parallel over all solver threads.
+// =========================================================================================================
+#define FA(k, t) SX(78 + (k), t)
+#define FR(k, t) FE(36 + (k), t)
+#define ROW(r, f) rows[(int64_t)(f) * rcap + (r)]
+template <int ROLE, int MODE>
+CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t rcap_in, const int32_t* tstart_in,
+                              const int Nt_in, const int h_tail_in, const int n_tail_in, const double sigma_in,
+                              const double rho_in) {
+  const Shm& sh = sh_in;
+  const double* rows = rows_in;
+  const int64_t rcap = rcap_in;
+  const int32_t* tstart = tstart_in;
+  const int Nt = Nt_in, Nm = Nt - 1, h_tail = h_tail_in, n_tail = n_tail_in;
+  const double sigma = sigma_in, rho_now = rho_in;
+  CSDO_SYNC();  // the row lanes' workspace writes (set-up stage / save) must be visible to the solver lanes
+  CSDO_SLANES(t) {
+    const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
+    CSDO_FOR(k, 4, {
+      const double cnk = WS(W_CN + k, t);
+      SH(carry, k, t) = (act & (1u << k)) ? rho_of_masks(eqm, lom, k, rho_now) * cnk * cnk : 0.0;
+    });
+  }
+  CSDO_SYNC();
+  CSDO_SLANES(t) {
+    const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
+    const int ncols = (t < Nm) ? 6 : 4;
+    {   // diagonal block
+      double A[21];
+      CSDO_FOR(k, 21, { A[k] = 0.0; });
+      CSDO_FOR(j, 6, { A[sym(j, j)] = (j < ncols) ? sigma : 1.0; });
+      A[sym(4, 4)] += WS(W_P + 0, t);
+      A[sym(5, 5)] += WS(W_P + 1, t);
+      if (t > 0) CSDO_FOR(k, 4, { A[sym(k, k)] += SH(carry, k, t - 1); });
+      CSDO_FOR(i, NROW, {
+        if (act & (1u << i)) {
+          const double rh = rho_of_masks(eqm, lom, i, rho_now);
+          double ci[3] = {0, 0, 0};
+          CSDO_FOR(s1, 3, {
+            if constexpr (row_col(i, s1) >= 0) ci[s1] = WS(W_C + 3 * i + s1, t);
+          });
+          CSDO_FOR(s1, 3, {
+            if constexpr (row_col(i, s1) >= 0) {
+              const double rc = rh * ci[s1];
+              CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, ci[s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
+            }
+          });
+        }
+      });
+      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
+        const double a = ROW(r, R_CA), bb = ROW(r, R_CB), cy = ROW(r, R_CY);
+        // inter rows have l = -inf and finite u: never loose, never equality (u - l = inf)
+        A[sym(0, 0)] = fma(rho_now * a, a, A[sym(0, 0)]);
+        A[sym(1, 0)] = fma(rho_now * bb, a, A[sym(1, 0)]);
+        A[sym(1, 1)] = fma(rho_now * bb, bb, A[sym(1, 1)]);
+        A[sym(2, 0)] = fma(rho_now * cy, a, A[sym(2, 0)]);
+        A[sym(2, 1)] = fma(rho_now * cy, bb, A[sym(2, 1)]);
+        A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
+      }
+      CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
+    }
+    CSDO_STAGE();
+    {   // coupling to t+1: kinematic rows (rho c_i c_next_i at [i][col]) and the v_t v_{t+1} term of P
+      double R[36];
+      CSDO_FOR(k, 36, { R[k] = 0.0; });
+      CSDO_FOR(i, 4, {
+        if (act & (1u << i)) {
+          const double rh = rho_of_masks(eqm, lom, i, rho_now);
+          const double cni = WS(W_CN + i, t);
+          CSDO_FOR(s1, 3, {
+            if constexpr (row_col(i, s1) >= 0) {
+              const double rc = rh * WS(W_C + 3 * i + s1, t);
+              R[i * 6 + row_col(i, s1)] = fma(rc, cni, R[i * 6 + row_col(i, s1)]);
+            }
+          });
+        }
+      });
+      R[4 * 6 + 4] += WS(W_P + 2, t);
+      const bool has_r = (t + 1) < Nt;
+      CSDO_FOR(k, 36, { FR(k, t) = has_r ? R[k] : 0.0; });
+    }
+  }
+  CSDO_SYNC();
+  for (int h = 1; h < h_tail; h <<= 1) {
+    const int m2 = 2 * h - 1;
+    CSDO_SLANES(t) {  // eliminated nodes
+      if ((t & m2) == h) {
+        const bool has_r = (t + h) < Nt;
+        double Sinv[21];
+        {
+          double Ain[21];
+          CSDO_FOR(k, 21, { Ain[k] = FA(k, t); });
+          spd_inverse6(Ain, Sinv);
+        }
+        CSDO_FOR(k, 21, { WS(W_SINV + k, t) = Sinv[k]; });
+        // T = Sinv * Rl   (rows: own vars, cols: left node's vars) = F_l, what the solve uses
+        double T[36];
+        {
+          double Rl[36];
+          CSDO_FOR(k, 36, { Rl[k] = FR(k, t - h); });
+          CSDO_FOR(r, 6, {
+            CSDO_FOR(c, 6, {
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rl[k * 6 + c], a); });
+              T[r * 6 + c] = a;
+              FE(r * 6 + c, t) = a;
+            });
+          });
+          // U_l = Rl' T  -> Schur update of the left neighbour's diagonal block
+          CSDO_FOR(a_, 6, {
+            CSDO_FOR(b_, a_ + 1, {
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], T[k * 6 + b_], a); });
+              SX(sym(a_, b_), t) = a;
+            });
+          });
+        }
+        CSDO_STAGE();
+        if (has_r) {
+          double Rr[36];
+          CSDO_FOR(k, 36, { Rr[k] = FR(k, t); });
+          // new coupling (right node <- left node) = -Rr * T
+          CSDO_FOR(a_, 6, {
+            CSDO_FOR(b_, 6, {
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], T[k * 6 + b_], a); });
+              SX(42 + a_ * 6 + b_, t) = -a;
+            });
+          });
+          CSDO_STAGE();
+          // V = Sinv * Rr'  (rows: own vars, cols: right node's vars); F_r = E_r * Sinv = V'
+          double Vm[36];
+          CSDO_FOR(r, 6, {
+            CSDO_FOR(c, 6, {
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rr[c * 6 + k], a); });
+              Vm[r * 6 + c] = a;
+            });
+          });
+          CSDO_FOR(a_, 6, {
+            CSDO_FOR(b_, a_ + 1, {
+              double a = 0.0;
+              CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], Vm[k * 6 + b_], a); });
+              SX(21 + sym(a_, b_), t) = a;
+            });
+          });
+          CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = Vm[r * 6 + c]; }); });
+        }
+      }
+    }
+    CSDO_SYNC();
+    CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements and take the coupling to their new right neighbour
+      if ((t & m2) == 0) {
+        double A[21];
+        CSDO_FOR(k, 21, { A[k] = FA(k, t); });
+        if (t >= h) CSDO_FOR(k, 21, { A[k] -= SX(21 + k, t - h); });
+        if ((t + h) < Nt) {
+          CSDO_FOR(k, 21, { A[k] -= SX(k, t + h); });
+          const bool has_rr = (t + 2 * h) < Nt;
+          CSDO_FOR(k, 36, { FR(k, t) = has_rr ? SX(42 + k, t + h) : 0.0; });
+        }
+        CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
+      }
+    }
+    CSDO_SYNC();
+  }
+  // ---- dense tail: the remaining nodes k * h_tail (k < R_tail) form a block-tridiagonal system with diagonal
+  // blocks FA and couplings FR.  It is assembled into LDS (sh.tinv, row r = 6k + i) and inverted in place by
+  // Gauss-Jordan elimination without pivoting (the matrix is SPD), one element per thread and pivot step; the rows
+  // of the inverse stay in LDS for the solves.  Rows / columns >= n_tail are zero.
+  CSDO_STHREADS(l, nthr) {
+    for (int e = l; e < TAIL_N * TAIL_N; e += nthr) {
+      const int r = e / TAIL_N, c = e - r * TAIL_N;
+      const int kn = r / 6, i = r - 6 * kn, jn = kn * h_tail;
+      const int kc = c / 6, ic = c - 6 * kc;
+      double v = 0.0;
+      if (r < n_tail && c < n_tail) {
+        if (kc == kn) v = FA((i >= ic) ? (i * (i + 1) / 2 + ic) : (ic * (ic + 1) / 2 + i), jn);
+        else if (kc == kn - 1) v = FR(i * 6 + ic, jn - h_tail);   // H(node kn, node kn-1)[i][ic]
+        else if (kc == kn + 1) v = FR(ic * 6 + i, jn);            // H(node kn+1, node kn)[ic][i]
+      }
+      SH(tinv, c, r) = v;
+    }
+  }
+  CSDO_SYNC();
+  for (int pv = 0; pv < n_tail; ++pv) {
+    // column pv (the eliminators) and the scaled pivot row go to a side buffer first: the update below overwrites both
+    CSDO_TLANES(t) {
+      const double dinv = 1.0 / SH(tinv, pv, pv);
+      sh.tvec[t] = SH(tinv, pv, t);
+      sh.tvec[TAIL_N + t] = (t == pv) ? dinv : SH(tinv, t, pv) * dinv;
+    }
+    CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {
+      for (int e = l; e < n_tail * n_tail; e += nthr) {
+        const int r = e / n_tail, c = e - r * n_tail;
+        const double pc = sh.tvec[TAIL_N + c];
+        double v;
+        if (r == pv) {
+          v = pc;
+        } else {
+          const double f = sh.tvec[r];
+          v = (c == pv) ? (-f * pc) : fma(-f, pc, SH(tinv, c, r));
+        }
+        SH(tinv, c, r) = v;
+      }
+    }
+    CSDO_SYNC();
+  }
+  CSDO_TLANES(t) {
+    if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });
+  }
+  CSDO_SYNC();
+}
+#undef FA
+#undef FR
+#undef ROW
+
+// =========================================================================================================
 template <int ROLE, int MODE, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out) {
@@ -142,7 +366,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   while ((Nt + h_tail - 1) / h_tail > TAIL_NODES) h_tail <<= 1;
   const int R_tail = (Nt + h_tail - 1) / h_tail, n_tail = 6 * R_tail;
 #if defined(CSDO_PROFILE_PHASES)
-  long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 16..23: factor sub-phases
   long long prof_last = (long long)__builtin_amdgcn_s_memtime();
   int prof_cur = 0;
   long long lvl_fwd = 0, lvl_bwd = 0;  // solver lane t == h: cycles inside its own elimination block
@@ -407,204 +631,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 
     double rho = osqp_min(osqp_max(P.rho0, RHO_MIN), RHO_MAX);
 
-    // ============================================================== BCR factorisation of H = P + sigma I + A' R A
-    // Runs on the solver lanes from the workspace copy of the scaled QP.
+    // BCR factorisation of H = P + sigma I + A' R A: bcr_factor above
     auto factor = [&](const double rho_now) __attribute__((always_inline)) {
       CSDO_MARK("factor_begin");
       CSDO_PHASE(5);
-      CSDO_SYNC();  // the row lanes' workspace writes (set-up stage / save) must be visible to the solver lanes
-      CSDO_SLANES(t) {
-        const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
-        CSDO_FOR(k, 4, {
-          const double cnk = WS(W_CN + k, t);
-          SH(carry, k, t) = (act & (1u << k)) ? rho_of_masks(eqm, lom, k, rho_now) * cnk * cnk : 0.0;
-        });
-      }
-      CSDO_SYNC();
-      CSDO_SLANES(t) {
-        SolvRegs& V = CSDO_SS(t);
-        const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
-        const int ncols = (t < Nm) ? 6 : 4;
-        double* A = V.fa;
-        double* R = V.fr;
-        CSDO_FOR(k, 21, { A[k] = 0.0; });
-        CSDO_FOR(k, 36, { R[k] = 0.0; });
-        CSDO_FOR(j, 6, { A[sym(j, j)] = (j < ncols) ? sigma : 1.0; });
-        A[sym(4, 4)] += WS(W_P + 0, t);
-        A[sym(5, 5)] += WS(W_P + 1, t);
-        if (t > 0) CSDO_FOR(k, 4, { A[sym(k, k)] += SH(carry, k, t - 1); });
-        CSDO_FOR(i, NROW, {
-          if (act & (1u << i)) {
-            const double rh = rho_of_masks(eqm, lom, i, rho_now);
-            double ci[3] = {0, 0, 0};
-            CSDO_FOR(s1, 3, {
-              if constexpr (row_col(i, s1) >= 0) ci[s1] = WS(W_C + 3 * i + s1, t);
-            });
-            double cni = 0.0;
-            if constexpr (i < 4) cni = WS(W_CN + i, t);
-            CSDO_FOR(s1, 3, {
-              if constexpr (row_col(i, s1) >= 0) {
-                const double rc = rh * ci[s1];
-                CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, ci[s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
-                if constexpr (i < 4) R[i * 6 + row_col(i, s1)] = fma(rc, cni, R[i * 6 + row_col(i, s1)]);
-              }
-            });
-          }
-        });
-        R[4 * 6 + 4] += WS(W_P + 2, t);
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double a = ROW(r, R_CA), bb = ROW(r, R_CB), cy = ROW(r, R_CY);
-          // inter rows have l = -inf and finite u: never loose, never equality (u - l = inf)
-          A[sym(0, 0)] = fma(rho_now * a, a, A[sym(0, 0)]);
-          A[sym(1, 0)] = fma(rho_now * bb, a, A[sym(1, 0)]);
-          A[sym(1, 1)] = fma(rho_now * bb, bb, A[sym(1, 1)]);
-          A[sym(2, 0)] = fma(rho_now * cy, a, A[sym(2, 0)]);
-          A[sym(2, 1)] = fma(rho_now * cy, bb, A[sym(2, 1)]);
-          A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
-        }
-      }
-      for (int h = 1; h < h_tail; h <<= 1) {
-        const int m2 = 2 * h - 1;
-        CSDO_SLANES(t) {  // every active node publishes its coupling to the right neighbour (= its E_r once eliminated)
-          SolvRegs& V = CSDO_SS(t);
-          if ((t & (h - 1)) == 0) {
-            const bool has_r = (t + h) < Nt;
-            CSDO_FOR(k, 36, { SH(facE, 36 + k, t) = has_r ? V.fr[k] : 0.0; });
-          }
-        }
-        CSDO_SYNC();
-        CSDO_SLANES(t) {  // eliminated nodes
-          SolvRegs& V = CSDO_SS(t);
-          if ((t & m2) == h) {
-            double Rl[36];
-            CSDO_FOR(k, 36, { Rl[k] = SH(facE, 36 + k, t - h); });
-            double Ain[21];
-            CSDO_FOR(k, 21, { Ain[k] = V.fa[k]; });
-            spd_inverse6(Ain, V.sinv);
-            CSDO_FOR(k, 21, { WS(W_SINV + k, t) = V.sinv[k]; });
-            // T = Sinv * Rl   (rows: own vars, cols: left node's vars)
-            double T[36];
-            CSDO_FOR(r, 6, {
-              CSDO_FOR(c, 6, {
-                double a = 0.0;
-                CSDO_FOR(k, 6, { a = fma(V.sinv[sym(r, k)], Rl[k * 6 + c], a); });
-                T[r * 6 + c] = a;
-                SH(facE, r * 6 + c, t) = a;   // F_l = Sinv * E_l: what the solve uses
-              });
-            });
-            // U_l = Rl' T  -> Schur update of the left neighbour's diagonal block
-            CSDO_FOR(a_, 6, {
-              CSDO_FOR(b_, a_ + 1, {
-                double a = 0.0;
-                CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], T[k * 6 + b_], a); });
-                SX(sym(a_, b_), t) = a;
-              });
-            });
-            if ((t + h) < Nt) {
-              const double* Rr = V.fr;
-              // V = Sinv * Rr'  (rows: own vars, cols: right node's vars)
-              double Vm[36];
-              CSDO_FOR(r, 6, {
-                CSDO_FOR(c, 6, {
-                  double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(V.sinv[sym(r, k)], Rr[c * 6 + k], a); });
-                  Vm[r * 6 + c] = a;
-                  SH(facE, 36 + c * 6 + r, t) = a;   // F_r = E_r * Sinv = (Sinv * E_r')'
-                });
-              });
-              CSDO_FOR(a_, 6, {
-                CSDO_FOR(b_, a_ + 1, {
-                  double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], Vm[k * 6 + b_], a); });
-                  SX(21 + sym(a_, b_), t) = a;
-                });
-              });
-              // new coupling (right node <- left node) = -Rr * T
-              CSDO_FOR(a_, 6, {
-                CSDO_FOR(b_, 6, {
-                  double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], T[k * 6 + b_], a); });
-                  SX(42 + a_ * 6 + b_, t) = -a;
-                });
-              });
-            }
-          }
-        }
-        CSDO_SYNC();
-        CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements
-          SolvRegs& V = CSDO_SS(t);
-          if ((t & m2) == 0) {
-            if (t >= h) CSDO_FOR(k, 21, { V.fa[k] -= SX(21 + k, t - h); });
-            if ((t + h) < Nt) {
-              CSDO_FOR(k, 21, { V.fa[k] -= SX(k, t + h); });
-              const bool has_rr = (t + 2 * h) < Nt;
-              CSDO_FOR(k, 36, { V.fr[k] = has_rr ? SX(42 + k, t + h) : 0.0; });
-            }
-          }
-        }
-      }
-      // ---- dense tail: the remaining nodes k * h_tail (k < R_tail) form a block-tridiagonal system with diagonal
-      // blocks fa and couplings fr.  Tail lane r = 6k + i (solver lanes 0 .. n_tail-1) assembles row r of that matrix,
-      // all tail lanes invert it together by Gauss-Jordan elimination without pivoting (the matrix is SPD) with the
-      // pivot row broadcast through LDS, and the rows of the inverse are parked in LDS for the solves.
-      CSDO_SLANES(t) {
-        SolvRegs& V = CSDO_SS(t);
-        if ((t & (h_tail - 1)) == 0) {
-          CSDO_FOR(k, 21, { SX(k, t) = V.fa[k]; });
-          const bool has_r = (t + h_tail) < Nt;
-          CSDO_FOR(k, 36, { SX(21 + k, t) = has_r ? V.fr[k] : 0.0; });
-        }
-      }
-      CSDO_SYNC();
-      CSDO_TLANES(t) {
-        SolvRegs& V = CSDO_SS(t);
-        {
-          const int kn = t / 6, i = t - 6 * kn, jn = kn * h_tail;
-          CSDO_FOR(c, TAIL_N, {
-            constexpr int kc = c / 6, ic = c % 6;
-            double v = 0.0;
-            if (c < n_tail) {
-              if (kc == kn) v = SX((i >= ic) ? (i * (i + 1) / 2 + ic) : (ic * (ic + 1) / 2 + i), jn);
-              else if (kc == kn - 1) v = SX(21 + i * 6 + ic, jn - h_tail);   // H(node kn, node kn-1)[i][ic]
-              else if (kc == kn + 1) v = SX(21 + ic * 6 + i, jn);            // H(node kn+1, node kn)[ic][i]
-            }
-            V.trow[c] = v;
-          });
-        }
-      }
-      for (int pv = 0; pv < n_tail; ++pv) {
-        CSDO_TLANES(t) {
-          SolvRegs& V = CSDO_SS(t);
-          if (t == pv) {
-            double piv = 0.0;
-            CSDO_FOR(c, TAIL_N, { piv = (c == pv) ? V.trow[c] : piv; });
-            const double dinv = 1.0 / piv;
-            CSDO_FOR(c, TAIL_N, {
-              V.trow[c] = (c == pv) ? dinv : V.trow[c] * dinv;
-              sh.tvec[TAIL_N + c] = V.trow[c];
-            });
-          }
-        }
-        CSDO_SYNC();
-        CSDO_TLANES(t) {
-          SolvRegs& V = CSDO_SS(t);
-          if (t != pv) {
-            double f = 0.0;
-            CSDO_FOR(c, TAIL_N, { f = (c == pv) ? V.trow[c] : f; });
-            CSDO_FOR(c, TAIL_N, {
-              const double pc = sh.tvec[TAIL_N + c];
-              V.trow[c] = (c == pv) ? (-f * pc) : fma(-f, pc, V.trow[c]);
-            });
-          }
-        }
-        CSDO_SYNC();
-      }
-      CSDO_TLANES(t) {
-        SolvRegs& V = CSDO_SS(t);
-        CSDO_FOR(c, TAIL_N, { SH(tinv, c, t) = V.trow[c]; });
-        if (t == 0) CSDO_FOR(k, 72, { SH(facE, k, 0) = 0.0; });
-      }
-      CSDO_SYNC();
+      bcr_factor<ROLE, MODE>(sh, rows, rcap, tstart, Nt, h_tail, n_tail, sigma, rho_now);
     };
 
     // ============================================================== BCR solve on the solver lanes.
@@ -1012,17 +1043,18 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // ---- the ADMM loop runs in blocks that end where osqp_solve would look at the iterate (termination check,
     // rho adaptation, iteration cap).  Inside a block only register state and the LDS 6-vectors are touched, plus the
     // inter-vehicle rows of the solver lanes.
-    // Inter-vehicle rows are spread evenly over the solver lanes, plane by plane (lane l takes planes l, l + Nt, ...:
-    // coalesced 32-byte field loads, at most ceil(K / Nt) planes per lane whatever their timesteps).  `plane_pass<UPDATE>`
+    // Inter-vehicle rows are spread evenly over ALL solver threads (also those beyond Nt), plane by plane (thread l takes
+    // planes l, l + nthr, ...: coalesced 32-byte field loads, at most ceil(K / nthr) planes per thread whatever their
+    // timesteps).  `plane_pass<UPDATE>`
     // optionally applies the z / y update with x_tilde of the plane's timestep (read from sh.vec) and leaves the
     // plane's share of A'(rho z - y) in pc[p][0..2]; the row lane of that timestep adds its planes' shares to its rhs.
     const int K_planes = ad.n_planes;
 #define PC(k, p) sh.pc[(p) * 3 + (k)]
-    auto plane_pass = [&](auto update_c, auto keep_c, const int lane, const double rho_now) __attribute__((always_inline)) {
+    auto plane_pass = [&](auto update_c, auto keep_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
       constexpr bool KEEP = decltype(keep_c)::value;
       const double rinv = 1.0 / rho_now;
-      for (int p = lane; p < K_planes; p += Nt) {
+      for (int p = lane; p < K_planes; p += nthr) {
         double zz[4], yy[4], ca[4], cb[4], cy[4], uu[4], xt[3] = {0, 0, 0};
         CSDO_FOR(q, 4, {
           zz[q] = ROW(4 * p + q, R_Z);
@@ -1091,30 +1123,28 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         S.eqmask = (unsigned)WS(W_EQ, t);
         S.loosemask = (unsigned)WS(W_LOOSE, t);
         S.ncols = (t < Nm) ? 6 : 4;
+        const double rho_eq0 = RHO_EQ_OVER_RHO_INEQ * rho;
+        CSDO_FOR(k, 4, {
+          SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq0, S.z[k], -S.y[k]) : 0.0;
+        });
       }
       CSDO_SLANES(t) {  // load the solver-lane cache and the inter-row share of the first rhs
         SolvRegs& V = CSDO_SS(t);
         if constexpr (MODE == 0) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
         CSDO_FOR(k, 36, {
-          V.el[k] = SH(facE, k, t);
-          if constexpr (MODE != 2) SH(er, k, t) = SH(facE, 36 + k, t);
+          V.el[k] = FE(k, t);
+          if constexpr (MODE != 2) SH(er, k, t) = FE(36 + k, t);
         });
-        plane_pass(std::false_type{}, std::false_type{}, t, rho);
       }
+      CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, l, nthr, rho); }
       CSDO_SYNC();
       const double rho_eq = RHO_EQ_OVER_RHO_INEQ * rho, rinv_in = 1.0 / rho, rinv_eq = 1.0 / rho_eq;
       auto iteration = [&](auto keep_c) __attribute__((always_inline)) {
         constexpr bool keep_dy = decltype(keep_c)::value;   // only the last iteration of a block records delta_y
         CSDO_PHASE(6);
         // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
+        // (the kinematic rows' share for t+1, sh.carry, was left by the previous update / the block's load)
         CSDO_MARK("rhs");
-        CSDO_LANES(t) {
-          LaneState& S = CSDO_LS(t);
-          CSDO_FOR(k, 4, {
-            SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq, S.z[k], -S.y[k]) : 0.0;
-          });
-        }
-        CSDO_SYNC();
         CSDO_LANES(t) {
           LaneState& S = CSDO_LS(t);
           double r6[6];
@@ -1138,8 +1168,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");
 #if !defined(CSDO_ABL_NOPLANES)
-        CSDO_SLANES(t) {  // inter-vehicle rows, concurrently with the row lanes below
-          plane_pass(std::true_type{}, keep_c, t, rho);
+        CSDO_STHREADS(l, nthr) {  // inter-vehicle rows, concurrently with the row lanes below
+          plane_pass(std::true_type{}, keep_c, l, nthr, rho);
         }
 #endif
         CSDO_LANES(t) {
@@ -1181,6 +1211,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           });
           CSDO_FOR(j, 6, {
             if (j < S.ncols) S.x[j] = alpha * xt[j] + (1.0 - alpha) * S.x[j];
+          });
+          // hand the kinematic rows' share of the next rhs to t+1 now: saves the next iteration a barrier
+          CSDO_FOR(k, 4, {
+            SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq, S.z[k], -S.y[k]) : 0.0;
           });
         }
         CSDO_SYNC();
@@ -1370,8 +1404,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   }
 #if defined(CSDO_PROFILE_PHASES)
   CSDO_PHASE(0);
-  if (threadIdx.x == 0 && B.prof)
+  if (threadIdx.x == 0 && B.prof) {
     for (int k = 0; k < 16; ++k) B.prof[(int64_t)agent * 48 + k] = prof_acc[k];
+    for (int k = 16; k < 24; ++k) B.prof[(int64_t)agent * 48 + 8 + k] = prof_acc[k];
+  }
   if constexpr (ROLE == ROLE_SOLVER) {
     const int ts = (int)threadIdx.x - (int)(blockDim.x >> 1);
     if (B.prof && ts > 0 && ts < Nt && (ts & (ts - 1)) == 0) {   // lanes 1, 2, 4, ...: eliminated at level log2(ts)
@@ -1391,6 +1427,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 
 #undef SH
 #undef SX
+#undef FE
 #undef ER
 #undef SINV
 #undef CD

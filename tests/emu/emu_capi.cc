@@ -49,27 +49,28 @@ extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_w
     Shm sh{};
     sh.stride = st;
     sh.vec = lds.data();
-    sh.pl = sh.vec + 6 * st;
-    sh.pr = sh.pl + 6 * st;
-    sh.carry = sh.pl;     // aliases, see Shm
-    sh.carry2 = sh.pr;
+    sh.pl = sh.vec;       // aliases, see Shm and dsqp_kernel_body.h
+    sh.pr = sh.vec + 6 * st;
+    sh.carry = sh.pr;
     sh.lohi = sh.pr + 6 * st;
     sh.red = sh.lohi;
     sh.sinvs = sh.lohi + 22 * st;
     sh.er = sh.sinvs + 22 * st;
+    sh.carry2 = sh.er;
     sh.obs = sh.er + 38 * st;
     sh.bcast = sh.obs + 3 * hb.max_obs;
     sh.tvec = sh.bcast + 32;
     sh.tinv = sh.tvec + 2 * TAIL_N;
     sh.pc = sh.tinv + TAIL_N * 38;
     std::vector<double> pc_ws;
-    if (mode == 1) {            // as dsqp_kernel_body.h: no bounds / pivot inverses in LDS, reductions over the E_r region
+    if (mode == 1) {            // no bounds / pivot inverses in LDS, reductions and hand-over in the E_r region
       sh.lohi = sh.sinvs = nullptr;
       sh.red = sh.er;
-    } else if (mode == 2) {     // only the 6-vectors and the reduction scratch
-      sh.sinvs = sh.er = nullptr;
-      sh.red = sh.lohi;
-      sh.lohi = nullptr;
+      sh.carry2 = sh.er + 12 * st;
+    } else if (mode == 2) {     // only the 6-vectors, the hand-over and the reduction scratch
+      sh.carry2 = sh.lohi;
+      sh.red = sh.carry2 + 6 * st;
+      sh.lohi = sh.sinvs = sh.er = nullptr;
       pc_ws.assign((size_t)3 * hb.max_planes + 1, 0.0);
       sh.pc = pc_ws.data();
     }

@@ -253,6 +253,13 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
 
 double csdo_dsqp_last_kernel_seconds(csdo_handle h) { return h ? h->last_kernel_s : 0.0; }
 
+int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents) {
+  if (!h || !h->uploaded || !group_of_agent || n_agents != (int32_t)h->order.size()) return CSDO_EINVAL;
+  for (int g = 0; g < (int)h->groups.size(); ++g)
+    for (int i = 0; i < h->groups[g].count; ++i) group_of_agent[h->order[h->groups[g].first + i]] = g;
+  return CSDO_OK;
+}
+
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode) {
   if (!h || mode < 0 || mode > 2) return CSDO_EINVAL;
   h->min_mode = mode;

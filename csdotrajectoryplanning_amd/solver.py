@@ -68,6 +68,13 @@ class DsqpHandle:
             check(n, "csdo_dsqp_launch_groups")
         return [{f: getattr(buf[i], f) for f, _ in abi.LaunchGroup._fields_} for i in range(min(n, 8))]
 
+    def agent_groups(self):
+        """Launch group of every agent of the uploaded batch, in upload order (csdo_dsqp_agent_groups)."""
+        n = sum(w.Na for w in self._keep)
+        out = np.zeros(n, np.int32)
+        check(lib().csdo_dsqp_agent_groups(self._h, abi.as_int32_p(out), n), "csdo_dsqp_agent_groups")
+        return out
+
     def download(self):
         worlds = self._keep
         sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]

@@ -34,5 +34,9 @@ def build_world(instance_file, seed=0, veh=None, parm=None, preprocess=None):
     return world, info
 
 
-def map100_world(k, veh=None, parm=None):
-    return build_world(MAP100_AGENTS50.format(k), seed=k, veh=veh, parm=parm)
+MAP100_SET_SIZE = 60   # benchmark/map100by100/agents50/obstacle holds ex0 .. ex59
+
+
+def map100_world(k, veh=None, parm=None, seed_offset=0):
+    """Instance ex{k} of the map100by100/agents50/obstacle set; the front-end stand-in is seeded with k + seed_offset."""
+    return build_world(MAP100_AGENTS50.format(k), seed=k + seed_offset, veh=veh, parm=parm)

@@ -138,6 +138,8 @@ typedef struct csdo_launch_group {
   double seconds;
 } csdo_launch_group;
 int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t cap);
+/* Which launch group every agent of the uploaded batch belongs to, in upload order (world 0's agents, world 1's, ...). */
+int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents);
 /* Testing / tuning knob: from the next upload on, no agent uses a residency mode below `mode` (0 restores the
  * automatic choice).  Results do not depend on the mode, only the speed does. */
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);

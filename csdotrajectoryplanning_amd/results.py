@@ -1,0 +1,160 @@
+"""Host-side tools on the output side of the DO path.
+
+write_solutions   the reference's result YAML (dumpSolutions, sqp/inter_agent_cons.cc:411-453): same keys in the same
+                  order (scripts/analysis_result.py reads the header positionally), %.3f, steer / omega in "degrees" with
+                  the reference's 180/3.14 factor, no v / omega on the last timestep.
+read_solutions    the inverse, for round-trip tests and for feeding the validator from a file.
+validate          independent geometric check of final trajectories in the spirit of scripts/collision_detection.py:
+                  vehicle rectangles against each other (separating axes) and against the circular obstacles, per
+                  timestep.  Own formulation, vectorised numpy; not on the hot path.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+_HEADER = ("cost", "makespan", "flowtime", "runtime", "runtime_search", "runtime_preprocess", "runtime_optimization",
+           "runtime_decentralized_optimization", "search_status", "solver_status")
+_DEG = 180 / 3.14   # the reference's constant, not pi
+
+
+def write_solutions(path, solutions, stats=None):
+    """solutions [Na][Nt][6] = x, y, yaw, steer, v, d_steer; stats: dict with any of the header keys (missing -> 0)."""
+    stats = stats or {}
+    sol = np.asarray(solutions, dtype=np.float64)
+    Na, Nt = sol.shape[:2]
+    out = ["statistics:"]
+    for k in _HEADER:
+        v = stats.get(k, 0)
+        out.append("  %s: %s" % (k, ("%d" % v) if k.endswith("_status") else ("%.3f" % float(v))))
+    out.append("schedule:")
+    for a in range(Na):
+        out.append("  agent%d:" % a)
+        for t in range(Nt):
+            x, y, yaw, steer, v, w = sol[a, t]
+            out.append("    - x: %.3f" % x)
+            out.append("      y: %.3f" % y)
+            out.append("      yaw: %.3f" % yaw)
+            out.append("      steer: %.3f" % (steer * _DEG))
+            out.append("      t: %d" % t)
+            if t == Nt - 1:
+                continue
+            out.append("      v: %.3f" % v)
+            out.append("      omega: %.3f" % (w * _DEG))
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+def read_solutions(path):
+    """Returns (solutions [Na][Nt][6], stats dict) from a file in the reference's result format."""
+    stats, agents, cur, rec = {}, [], None, None
+    section = None
+    with open(path) as f:
+        for raw in f:
+            line = raw.rstrip("\n")
+            if not line.strip():
+                continue
+            if line.startswith("statistics:"):
+                section = "stat"
+                continue
+            if line.startswith("schedule:"):
+                section = "sched"
+                continue
+            body = line.strip()
+            if section == "stat":
+                k, v = body.split(":", 1)
+                stats[k.strip()] = float(v)
+            elif section == "sched":
+                if body.startswith("agent") and body.endswith(":"):
+                    cur = []
+                    agents.append(cur)
+                    continue
+                if body.startswith("- "):
+                    rec = {}
+                    cur.append(rec)
+                    body = body[2:]
+                k, v = body.split(":", 1)
+                rec[k.strip()] = float(v)
+    Na, Nt = len(agents), max(len(a) for a in agents)
+    sol = np.zeros((Na, Nt, 6))
+    for a, recs in enumerate(agents):
+        for t, r in enumerate(recs):
+            sol[a, t] = [r["x"], r["y"], r["yaw"], r["steer"] / _DEG, r.get("v", 0.0), r.get("omega", 0.0) / _DEG]
+    return sol, stats
+
+
+@dataclass
+class ValidationReport:
+    vehicle_collisions: int          # (timestep, i, j) triples with overlapping rectangles
+    obstacle_collisions: int         # (timestep, agent, obstacle) triples
+    out_of_map: int                  # (timestep, agent) pairs with a rectangle corner outside the map
+    first_vehicle_collision: tuple   # (t, i, j) or None
+    first_obstacle_collision: tuple  # (t, agent, obstacle) or None
+    min_obstacle_clearance: float    # smallest distance rectangle - obstacle disc over the trajectory (negative: overlap)
+
+    @property
+    def ok(self):
+        return self.vehicle_collisions == 0 and self.obstacle_collisions == 0 and self.out_of_map == 0
+
+
+def _rect_frames(sol, veh):
+    """Centres [Na,Nt,2], unit heading [Na,Nt,2], half length, half width of the vehicle rectangles.  The reference point
+    (x, y) sits LB in front of the rear bumper: the body spans [-LB, +LF] along the heading (common/motion_planning.h)."""
+    x, y, yaw = sol[..., 0], sol[..., 1], sol[..., 2]
+    u = np.stack([np.cos(yaw), np.sin(yaw)], -1)
+    c = np.stack([x, y], -1) + 0.5 * (veh.LF - veh.LB) * u
+    return c, u, 0.5 * (veh.LF + veh.LB), 0.5 * veh.car_width
+
+
+def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0) -> ValidationReport:
+    """solutions [Na][Nt][>=3]; obstacles [n][3] = x, y, r.  `margin` inflates every vehicle rectangle on all sides."""
+    sol = np.asarray(solutions, dtype=np.float64)
+    Na, Nt = sol.shape[:2]
+    c, u, hl, hw = _rect_frames(sol, veh)
+    hl, hw = hl + margin, hw + margin
+    n = np.stack([-u[..., 1], u[..., 0]], -1)                       # unit normal
+    # ---- rectangle / rectangle: separating axes = the two axes of either rectangle
+    veh_hits, first_v = 0, None
+    if Na > 1:
+        d = c[None, :, :, :] - c[:, None, :, :]                     # [i, j, t, 2]  centre j - centre i
+        def gap(axis_owner):                                        # axes of rectangle i (0) or j (1), both axes at once
+            ua = u[:, None] if axis_owner == 0 else u[None, :]
+            na = n[:, None] if axis_owner == 0 else n[None, :]
+            uo = u[None, :] if axis_owner == 0 else u[:, None]
+            no = n[None, :] if axis_owner == 0 else n[:, None]
+            ext_u = hl * np.abs((uo * ua).sum(-1)) + hw * np.abs((no * ua).sum(-1)) + hl
+            ext_n = hl * np.abs((uo * na).sum(-1)) + hw * np.abs((no * na).sum(-1)) + hw
+            return np.abs((d * ua).sum(-1)) <= ext_u, np.abs((d * na).sum(-1)) <= ext_n
+        a1, a2 = gap(0)
+        b1, b2 = gap(1)
+        overlap = a1 & a2 & b1 & b2                                 # no separating axis
+        iu = np.triu_indices(Na, 1)
+        ov = overlap[iu]                                            # [pairs, t]
+        veh_hits = int(ov.sum())
+        if veh_hits:
+            p, t = np.argwhere(ov)[np.argmin(np.argwhere(ov)[:, 1])]
+            first_v = (int(t), int(iu[0][p]), int(iu[1][p]))
+    # ---- circle / rectangle: distance from the disc centre to the rectangle in the rectangle's frame
+    obs_hits, first_o, clearance = 0, None, np.inf
+    if obstacles is not None and len(obstacles):
+        ob = np.asarray(obstacles, dtype=np.float64).reshape(-1, 3)
+        rel = ob[None, None, :, :2] - c[:, :, None, :]               # [a, t, o, 2]
+        lx = np.abs((rel * u[:, :, None, :]).sum(-1)) - hl
+        ly = np.abs((rel * n[:, :, None, :]).sum(-1)) - hw
+        outside = np.hypot(np.maximum(lx, 0), np.maximum(ly, 0))
+        inside = np.minimum(np.maximum(lx, ly), 0)
+        dist = outside + inside - ob[None, None, :, 2]
+        clearance = float(dist.min())
+        hit = dist < 0
+        obs_hits = int(hit.sum())
+        if obs_hits:
+            idx = np.argwhere(hit)
+            a, t, o = idx[np.argmin(idx[:, 1])]
+            first_o = (int(t), int(a), int(o))
+    out = 0
+    if dimx is not None and dimy is not None:
+        corners = [c + sx * hl * u + sy * hw * n for sx in (-1, 1) for sy in (-1, 1)]
+        bad = np.zeros((Na, Nt), bool)
+        for k in corners:
+            bad |= (k[..., 0] < 0) | (k[..., 0] > dimx) | (k[..., 1] < 0) | (k[..., 1] > dimy)
+        out = int(bad.sum())
+    return ValidationReport(veh_hits, obs_hits, out, first_v, first_o, clearance)

@@ -201,3 +201,41 @@ def test_solver_dsqp_mirror(oracle, veh_parm):
     assert s.get_initial_static_legal() == bool(z["initial_static_legal"])
     assert np.array_equal(s.num_iterations, z["sqp_iters"]) and s.getMaxOfRuntimes() > 0
     np.testing.assert_allclose(s.solutions, z["solutions"], atol=parity.CORRIDOR_FLIP_TOL)
+
+
+@pytest.mark.parametrize("n_obs", [40, 300])
+def test_gpu_corridor_boxes_bit_exact_in_dense_obstacle_fields(gpu_handle, oracle, veh_parm, n_obs):
+    """> 8 obstacles near a seed (register slots of grow_box) and > 256 obstacles (its cull mask): same boxes."""
+    veh, _ = veh_parm
+    rng = np.random.default_rng(11 + n_obs)
+    side = 30.0
+    obstacles = np.column_stack([rng.uniform(2, side - 2, n_obs), rng.uniform(2, side - 2, n_obs),
+                                 rng.uniform(0.2, 0.6, n_obs)])
+    pts = rng.uniform(0, side, (300, 2))
+    bo, so = oracle.generate_boxes(pts, obstacles, side, side, veh)
+    bg, sg = gpu_handle.generate_boxes(pts, obstacles, side, side, veh)
+    assert np.array_equal(so, sg)
+    legal = (so >> 1) != 2
+    assert np.array_equal(bo[legal], bg[legal])
+    np.testing.assert_allclose(bo[~legal], bg[~legal], atol=1e-9, rtol=0)
+
+
+def test_gpu_mixed_batch_launch_groups(gpu_handle, veh_parm):
+    """A batch whose worlds fall into different kernel classes (Nt = 91: 256-thread workgroups, Nt = 169: 512) is split
+    into concurrent launch groups; every agent is in exactly one and the results equal separate solves."""
+    veh, parm = veh_parm
+    w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    w2, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)
+    gpu_handle.upload([w1, w2, w1])
+    t = gpu_handle.run()
+    groups, of = gpu_handle.launch_groups(), gpu_handle.agent_groups()
+    got = gpu_handle.download()
+    assert len(groups) == 2 and sorted(g["threads"] for g in groups) == [256, 512]
+    assert sum(g["n_agents"] for g in groups) == 2 * w1.Na + w2.Na == len(of)
+    assert all(0 < g["seconds"] <= t * 1.01 for g in groups)
+    g256 = [i for i, g in enumerate(groups) if g["threads"] == 256][0]
+    assert np.all(of[:w1.Na] == g256) and np.all(of[w1.Na:w1.Na + w2.Na] == 1 - g256) and np.all(of[-w1.Na:] == g256)
+    for w, b in zip((w1, w2, w1), got):
+        s = gpu_handle.solve(w)
+        assert np.array_equal(s.solutions, b.solutions) and np.array_equal(s.admm_iters, b.admm_iters)
+        assert b.agent_seconds.shape == (w.Na,) and np.all(b.agent_seconds > 0)

@@ -98,3 +98,21 @@ def test_corridor_boxes_bit_exact(oracle, emu, veh_parm):
     assert np.array_equal(bo[legal], be[legal])
     np.testing.assert_allclose(bo[~legal], be[~legal], atol=1e-9, rtol=0)
     assert (~legal).sum() > 0 and ((so >> 1) == 1).sum() > 0
+
+
+@pytest.mark.parametrize("n_obs", [40, 300])
+def test_corridor_boxes_bit_exact_in_dense_obstacle_fields(oracle, emu, veh_parm, n_obs):
+    """More obstacles near a seed point than the growth loop holds in registers (8), and more obstacles than its cull
+    mask holds (256): the slower paths of grow_box give the same boxes bit for bit."""
+    veh, _ = veh_parm
+    rng = np.random.default_rng(11 + n_obs)
+    side = 30.0
+    obstacles = np.column_stack([rng.uniform(2, side - 2, n_obs), rng.uniform(2, side - 2, n_obs),
+                                 rng.uniform(0.2, 0.6, n_obs)])
+    pts = rng.uniform(0, side, (300, 2))
+    bo, so = oracle.generate_boxes(pts, obstacles, side, side, veh)
+    be, se = emu.generate_boxes(pts, obstacles, side, side, veh)
+    assert np.array_equal(so, se)
+    legal = (so >> 1) != 2
+    assert legal.sum() > 20 and np.array_equal(bo[legal], be[legal])
+    np.testing.assert_allclose(bo[~legal], be[~legal], atol=1e-9, rtol=0)

@@ -68,6 +68,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
 
+    # torch first: it brings its own HIP runtime, which must be the one libcsdo_hip.so binds to (loading the library
+    # before torch puts two runtimes into the process and aborts under rocprofv3); importing does not touch the GPU
+    import torch
+
     # ---- workload (host side, before anything touches the GPU: the pool forks) ----
     from multiprocessing import get_context
     n_inst = max(1, min(args.instances, 60))
@@ -83,7 +87,6 @@ def main():
     t_pre = time.perf_counter() - t_pre0
 
     import numpy as np
-    import torch
     from csdotrajectoryplanning_amd.solver import DsqpHandle, interpolate_and_planes
     from csdotrajectoryplanning_amd.synth import GENERATOR_NAME
 

@@ -8,13 +8,16 @@ namespace csdo {
 // strides 6 and 73 doubles are bank-conflict free for the b64/b128 reads of neighbouring and of 2h-strided lanes)
 #define SH(arr, k, t) sh.arr[(t) * LD_##arr + (k)]
 // factor-time exchange lives in global memory, coalesced [k][stride]
-#define SX(k, t) sh.facX[(k) * sh.stride + (t)]
-#define FE(k, t) sh.facE[(t) * 72 + (k)]   // lane-major: one address register + immediate offsets (SoA measured slower)
+// (uniform base + field offset)[lane]: the field part stays scalar and the lane part is one unsigned 32-bit register, so
+// the access is `global_load v, v_lane, s[base]` - no per-field 64-bit address in vector registers (the compiler
+// otherwise hoists those out of the loops and spills them: a scratch reload in front of every workspace access)
+#define SX(k, t) (sh.facX + (size_t)(k) * (size_t)sh.stride)[(unsigned)(t)]
+#define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
 // E_r of node t: LDS copy, or the workspace copy for long horizons
 #define ER(k, t) (MODE == 2 ? FE(36 + (k), t) : SH(er, k, t))
 #define SINV(k, t) (MODE != 0 ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
-#define CD(slot, t) sh.cold[(slot) * sh.stride + (t)]
-#define WS(slot, t) sh.cold[(slot) * sh.stride + (t)]
+#define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
+#define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 
 // ---------------------------------------------------------------------------------------------------------
 // Assembly of the home rows of timestep t at the linearisation point S.sol0 (unscaled values).
@@ -117,7 +120,7 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 // =========================================================================================================
 #define FA(k, t) SX(78 + (k), t)
 #define FR(k, t) FE(36 + (k), t)
-#define ROW(r, f) rows[(int64_t)(f) * rcap + (r)]
+#define ROW(r, f) (rows + (int64_t)(f) * rcap)[(unsigned)(r)]
 template <int ROLE, int MODE>
 CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t rcap_in, const int32_t* tstart_in,
                               const int Nt_in, const int h_tail_in, const int n_tail_in, const double sigma_in,
@@ -208,58 +211,127 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           spd_inverse6(Ain, Sinv);
         }
         CSDO_FOR(k, 21, { WS(W_SINV + k, t) = Sinv[k]; });
-        // T = Sinv * Rl   (rows: own vars, cols: left node's vars) = F_l, what the solve uses
-        double T[36];
-        {
-          double Rl[36];
-          CSDO_FOR(k, 36, { Rl[k] = FR(k, t - h); });
-          CSDO_FOR(r, 6, {
-            CSDO_FOR(c, 6, {
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rl[k * 6 + c], a); });
-              T[r * 6 + c] = a;
-              FE(r * 6 + c, t) = a;
+        if constexpr (MODE != 2) {
+          // Register-lean order: the 6x6 products T = Sinv Rl and V = Sinv Rr' are parked in this lane's (idle) E_r slot
+          // of LDS as they are produced and read back column by column, so that one 6x6 operand, the pivot inverse and a
+          // handful of accumulators are all that is live (the all-register version below spills, and a spilled double
+          // costs an L2 round trip).  Same products, same summation order, same results.
+#define STASH(k) SH(er, k, t)
+          {
+            double Rl[36];
+            CSDO_FOR(k, 36, { Rl[k] = FR(k, t - h); });
+            CSDO_FOR(r, 6, {
+              CSDO_FOR(c, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rl[k * 6 + c], a); });
+                STASH(r * 6 + c) = a;
+                FE(r * 6 + c, t) = a;      // F_l = Sinv * E_l, what the solve uses
+              });
             });
-          });
-          // U_l = Rl' T  -> Schur update of the left neighbour's diagonal block
-          CSDO_FOR(a_, 6, {
-            CSDO_FOR(b_, a_ + 1, {
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], T[k * 6 + b_], a); });
-              SX(sym(a_, b_), t) = a;
+            CSDO_STAGE();
+            CSDO_FOR(b_, 6, {              // U_l = Rl' T, column b of T at a time
+              double tc[6];
+              CSDO_FOR(k, 6, { tc[k] = STASH(k * 6 + b_); });
+              CSDO_FOR(a_, 6, {
+                if constexpr (a_ >= b_) {
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], tc[k], a); });
+                  SX(sym(a_, b_), t) = a;
+                }
+              });
             });
-          });
-        }
-        CSDO_STAGE();
-        if (has_r) {
-          double Rr[36];
-          CSDO_FOR(k, 36, { Rr[k] = FR(k, t); });
-          // new coupling (right node <- left node) = -Rr * T
-          CSDO_FOR(a_, 6, {
-            CSDO_FOR(b_, 6, {
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], T[k * 6 + b_], a); });
-              SX(42 + a_ * 6 + b_, t) = -a;
-            });
-          });
+          }
           CSDO_STAGE();
-          // V = Sinv * Rr'  (rows: own vars, cols: right node's vars); F_r = E_r * Sinv = V'
-          double Vm[36];
-          CSDO_FOR(r, 6, {
-            CSDO_FOR(c, 6, {
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rr[c * 6 + k], a); });
-              Vm[r * 6 + c] = a;
+          if (has_r) {
+            double Rr[36];
+            CSDO_FOR(k, 36, { Rr[k] = FR(k, t); });
+            CSDO_FOR(b_, 6, {              // new coupling (right node <- left node) = -Rr * T
+              double tc[6];
+              CSDO_FOR(k, 6, { tc[k] = STASH(k * 6 + b_); });
+              CSDO_FOR(a_, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], tc[k], a); });
+                SX(42 + a_ * 6 + b_, t) = -a;
+              });
             });
-          });
-          CSDO_FOR(a_, 6, {
-            CSDO_FOR(b_, a_ + 1, {
-              double a = 0.0;
-              CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], Vm[k * 6 + b_], a); });
-              SX(21 + sym(a_, b_), t) = a;
+            CSDO_STAGE();
+            CSDO_FOR(r, 6, {               // V = Sinv * Rr'; F_r = E_r * Sinv = V'
+              CSDO_FOR(c, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rr[c * 6 + k], a); });
+                STASH(r * 6 + c) = a;
+              });
             });
-          });
-          CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = Vm[r * 6 + c]; }); });
+            CSDO_STAGE();
+            CSDO_FOR(b_, 6, {              // U_r = Rr V, column b of V at a time
+              double vc[6];
+              CSDO_FOR(k, 6, { vc[k] = STASH(k * 6 + b_); });
+              CSDO_FOR(a_, 6, {
+                if constexpr (a_ >= b_) {
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], vc[k], a); });
+                  SX(21 + sym(a_, b_), t) = a;
+                }
+              });
+            });
+            CSDO_STAGE();
+            CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = STASH(r * 6 + c); }); });
+          }
+#undef STASH
+        } else {
+          // T = Sinv * Rl   (rows: own vars, cols: left node's vars) = F_l, what the solve uses
+          double T[36];
+          {
+            double Rl[36];
+            CSDO_FOR(k, 36, { Rl[k] = FR(k, t - h); });
+            CSDO_FOR(r, 6, {
+              CSDO_FOR(c, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rl[k * 6 + c], a); });
+                T[r * 6 + c] = a;
+                FE(r * 6 + c, t) = a;
+              });
+            });
+            // U_l = Rl' T  -> Schur update of the left neighbour's diagonal block
+            CSDO_FOR(a_, 6, {
+              CSDO_FOR(b_, a_ + 1, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], T[k * 6 + b_], a); });
+                SX(sym(a_, b_), t) = a;
+              });
+            });
+          }
+          CSDO_STAGE();
+          if (has_r) {
+            double Rr[36];
+            CSDO_FOR(k, 36, { Rr[k] = FR(k, t); });
+            // new coupling (right node <- left node) = -Rr * T
+            CSDO_FOR(a_, 6, {
+              CSDO_FOR(b_, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], T[k * 6 + b_], a); });
+                SX(42 + a_ * 6 + b_, t) = -a;
+              });
+            });
+            CSDO_STAGE();
+            // V = Sinv * Rr'  (rows: own vars, cols: right node's vars); F_r = E_r * Sinv = V'
+            double Vm[36];
+            CSDO_FOR(r, 6, {
+              CSDO_FOR(c, 6, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rr[c * 6 + k], a); });
+                Vm[r * 6 + c] = a;
+              });
+            });
+            CSDO_FOR(a_, 6, {
+              CSDO_FOR(b_, a_ + 1, {
+                double a = 0.0;
+                CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], Vm[k * 6 + b_], a); });
+                SX(21 + sym(a_, b_), t) = a;
+              });
+            });
+            CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = Vm[r * 6 + c]; }); });
+          }
         }
       }
     }
@@ -377,7 +449,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #define CSDO_LVL_END(acc) ((void)0)
 #endif
 
-#define ROW(r, f) rows[(int64_t)(f) * rcap + (r)]
+#define ROW(r, f) (rows + (int64_t)(f) * rcap)[(unsigned)(r)]
 
   // ---------------------------------------------------------------- phase 0: stage obstacles, load the guess
   CSDO_LANES(t) {

@@ -38,19 +38,26 @@
 // second): blocks of the other role are compiled out, so each instantiation only carries its own register state.
 // Both instantiations execute the same barrier sequence and derive every uniform control value (iteration counts,
 // status, rho, norms) from the same LDS broadcasts.
-#define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = (int)threadIdx.x; t < Nt)
+// The lane index of every lanes-block passes through an empty asm: the compiler can then neither hoist the per-field
+// workspace / LDS addresses of a block to the top of the program nor keep them alive across blocks (it did: hundreds of
+// 64-bit addresses in vector registers, spilled, and reloaded from scratch in front of the accesses).
+__device__ __forceinline__ int csdo_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = csdo_opaque((int)threadIdx.x); t < Nt)
 // ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
 #define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
 #define CSDO_SLANES(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0 && t < Nt)
 // tail lanes: solver threads [base, base + n_tail), independent of Nt (n_tail <= 36)
 #define CSDO_TLANES(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0 && t < n_tail)
 // every thread of the solver half, whatever Nt (element-parallel work: t in [0, nthr))
 #define CSDO_STHREADS(t, nthr)                                                              \
   if constexpr (ROLE != ROLE_ROW)                                                           \
     if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
-      if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0)
+      if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0)
 #define CSDO_LS(t) lanes_r
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()

@@ -58,6 +58,17 @@ __device__ __forceinline__ int csdo_opaque(int v) {
   if constexpr (ROLE != ROLE_ROW)                                                           \
     if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
       if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0)
+// blocks of the ADMM iteration keep the plain lane index: their addresses are few and live in registers for the whole
+// block of iterations
+#define CSDO_LANES_HOT(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = (int)threadIdx.x; t < Nt)
+#define CSDO_SLANES_HOT(t) \
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
+#define CSDO_TLANES_HOT(t) \
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
+#define CSDO_STHREADS_HOT(t, nthr)                                                          \
+  if constexpr (ROLE != ROLE_ROW)                                                           \
+    if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
+      if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0)
 #define CSDO_LS(t) lanes_r
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
@@ -86,6 +97,10 @@ __device__ __forceinline__ int csdo_opaque(int v) {
 #define CSDO_TLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < n_tail; ++t)
 #define CSDO_STHREADS(t, nthr) \
   if constexpr (ROLE != ROLE_ROW) if (const int nthr = 64; true) for (int t = 0; t < nthr; ++t)
+#define CSDO_LANES_HOT(t) CSDO_LANES(t)
+#define CSDO_SLANES_HOT(t) CSDO_SLANES(t)
+#define CSDO_TLANES_HOT(t) CSDO_TLANES(t)
+#define CSDO_STHREADS_HOT(t, nthr) CSDO_STHREADS(t, nthr)
 #define CSDO_LS(t) lanes_r[t]
 #define CSDO_SS(t) lanes_s[t]
 #define CSDO_SYNC() ((void)0)

@@ -1217,7 +1217,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
         // (the kinematic rows' share for t+1, sh.carry, was left by the previous update / the block's load)
         CSDO_MARK("rhs");
-        CSDO_LANES(t) {
+        CSDO_LANES_HOT(t) {
           LaneState& S = CSDO_LS(t);
           double r6[6];
           CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
@@ -1240,11 +1240,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");
 #if !defined(CSDO_ABL_NOPLANES)
-        CSDO_STHREADS(l, nthr) {  // inter-vehicle rows, concurrently with the row lanes below
+        CSDO_STHREADS_HOT(l, nthr) {  // inter-vehicle rows, concurrently with the row lanes below
           plane_pass(std::true_type{}, keep_c, l, nthr, rho);
         }
 #endif
-        CSDO_LANES(t) {
+        CSDO_LANES_HOT(t) {
           LaneState& S = CSDO_LS(t);
           double xt[6], xn[4] = {0, 0, 0, 0};
           CSDO_FOR(k, 6, { xt[k] = SH(vec, k, t); });

@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --setup-procs 1"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --setup-procs 1 --skip-single-instance"
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace -o trace -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_trace.log 2>&1
 timeout -s KILL 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_fetch.log 2>&1
 timeout -s KILL 900 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o write -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_write.log 2>&1

@@ -54,7 +54,7 @@ if summary:
         # 8-B-per-lane accesses, which the guide calls uncalibrated); WRITE_SIZE is taken as is.
         summary["hbm_bytes_per_launch_dominant_kernel"] = 2.0 * f_kib * 1024.0 + w_kib * 1024.0
     summary["_note"] = ("rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes), command: "
-                        "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --setup-procs 1; per-dispatch means over the "
+                        "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --setup-procs 1 --skip-single-instance; per-dispatch means over the "
                         "dsqp_agent_kernel dispatches; 'dominant' = the <512, 0, true> instantiation")
     with open(os.path.join(out_dir, "%s_pmc_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)

@@ -49,14 +49,16 @@ struct csdo_handle_s {
   // launch groups (dsqp_launch.h): group 0 runs on the caller's stream, the others concurrently on side streams
   std::vector<LaunchGroup> groups;
   int min_mode = 0;            // csdo_dsqp_set_min_residency_mode
+  int n_cu = 256;              // compute units of the device: persistent workgroups per launch group
   std::vector<int32_t> order;
   std::vector<hipStream_t> side;
-  std::vector<hipEvent_t> g_begin, g_end;
+  std::vector<hipEvent_t> g_begin, g_end, g_zeroed, g_end2;
+  std::vector<hipStream_t> side2;   // streams of the groups' second (elastic) launches
   HostBatch hb;
   bool uploaded = false;
   int n_worlds = 0;
   double last_kernel_s = 0.0;
-  DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d;
+  DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d, queues;
   DevBuf box_pts, box_obs, box_out, box_status;
   DevBuf prof;
   std::vector<double> h_sol, h_corr;
@@ -90,8 +92,11 @@ static int build_groups(csdo_handle h) {
   h->order.resize(Na);
   for (int a = 0; a < Na; ++a) h->order[a] = a;
   std::stable_sort(h->order.begin(), h->order.end(), [&](int p, int q) {
-    if (key[p].block != key[q].block) return key[p].block < key[q].block;
-    if (key[p].mode != key[q].mode) return key[p].mode < key[q].mode;   // the faster, LDS-resident class first
+    // groups are launched in this order and the first launch gets the CUs first (each group launches one persistent
+    // workgroup per CU): the classes whose agents run longest - workspace-resident modes, long horizons - go first, so
+    // that their longest agents start at once and the faster classes fill the CUs they release
+    if (key[p].mode != key[q].mode) return key[p].mode > key[q].mode;
+    if (key[p].block != key[q].block) return key[p].block > key[q].block;
     return hb.est_work[p] > hb.est_work[q];
   });
   h->groups.clear();
@@ -115,10 +120,16 @@ static int build_groups(csdo_handle h) {
     h->side.push_back(s);
   }
   while (h->g_begin.size() < h->groups.size()) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CSDO_EDEVICE;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    hipStream_t s2 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess ||
+        hipEventCreate(&e3) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess)
+      return CSDO_EDEVICE;
     h->g_begin.push_back(e0);
     h->g_end.push_back(e1);
+    h->g_zeroed.push_back(e2);
+    h->g_end2.push_back(e3);
+    h->side2.push_back(s2);
   }
   return CSDO_OK;
 }
@@ -136,6 +147,8 @@ int csdo_dsqp_create(csdo_handle* out, int device_ordinal) {
   csdo_handle h = new (std::nothrow) csdo_handle_s();
   if (!h) return CSDO_ENOMEM;
   h->device = device_ordinal;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) h->n_cu = cus;
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;
@@ -150,12 +163,15 @@ void csdo_dsqp_destroy(csdo_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
-                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->box_pts,
+                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->queues, &h->box_pts,
                     &h->box_obs, &h->box_out, &h->box_status})
     b->release();
   for (hipStream_t s : h->side) (void)hipStreamDestroy(s);
   for (hipEvent_t e : h->g_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_end) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->g_zeroed) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->g_end2) (void)hipEventDestroy(e);
+  for (hipStream_t s : h->side2) (void)hipStreamDestroy(s);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -185,6 +201,33 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   if ((rc = build_groups(h)) != CSDO_OK) return rc;
   UP(order_d, h->order);
 #undef UP
+  if ((rc = h->queues.ensure(h->groups.size() * 64)) != CSDO_OK) return rc;   // one counter per group, a cache line apart
+  for (size_t g = 0; g < h->groups.size(); ++g) {
+    h->groups[g].queue = (int*)((char*)h->queues.p + g * 64);
+  }
+  // CU shares: every group first launches its share of the CUs (by estimated work; workspace-resident modes iterate
+  // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
+  // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
+  {
+    const double mode_cost[3] = {1.0, 1.7, 2.5};
+    std::vector<double> work(h->groups.size(), 0.0);
+    double total = 0.0;
+    for (size_t g = 0; g < h->groups.size(); ++g) {
+      for (int i = 0; i < h->groups[g].count; ++i) work[g] += hb.est_work[h->order[h->groups[g].first + i]];
+      work[g] *= mode_cost[h->groups[g].mode];
+      total += work[g];
+    }
+    int left = h->n_cu;
+    for (size_t g = 0; g < h->groups.size(); ++g) {
+      LaunchGroup& G = h->groups[g];
+      const int cap = std::min(G.count, h->n_cu);
+      int n = (g + 1 == h->groups.size()) ? left : (int)std::lround(h->n_cu * work[g] / std::max(total, 1e-30));
+      n = std::max(1, std::min(n, std::min(cap, std::max(left, 1))));
+      G.primary = n;
+      G.elastic = cap - n;
+      left -= n;
+    }
+  }
   if ((rc = h->rows_ws.ensure((size_t)hb.rows_total * ROWS_WS_STRIDE * sizeof(double))) != CSDO_OK) return rc;
   if ((rc = h->fac_ws.ensure((size_t)hb.fac_total * sizeof(double))) != CSDO_OK) return rc;
   if ((rc = h->sol.ensure((size_t)hb.steps_total * 6 * sizeof(double))) != CSDO_OK) return rc;
@@ -235,8 +278,17 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
     hipStream_t gs = g == 0 ? s : h->side[g - 1];
     if (g > 0) HIP_OK(hipStreamWaitEvent(gs, h->ev0, 0), CSDO_EDEVICE);
     HIP_OK(hipEventRecord(h->g_begin[g], gs), CSDO_EDEVICE);
-    if (launch_dsqp(h->dev, h->groups[g], gs) != hipSuccess) return CSDO_EDEVICE;
+    HIP_OK(hipMemsetAsync(h->groups[g].queue, 0, sizeof(int), gs), CSDO_EDEVICE);
+    HIP_OK(hipEventRecord(h->g_zeroed[g], gs), CSDO_EDEVICE);
+    if (launch_dsqp(h->dev, h->groups[g], h->groups[g].primary, gs) != hipSuccess) return CSDO_EDEVICE;
     HIP_OK(hipEventRecord(h->g_end[g], gs), CSDO_EDEVICE);
+  }
+  for (int g = 0; g < ng; ++g) {   // second launches: same queues, workgroups that start on CUs other groups release
+    if (h->groups[g].elastic <= 0) continue;
+    HIP_OK(hipStreamWaitEvent(h->side2[g], h->g_zeroed[g], 0), CSDO_EDEVICE);
+    if (launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, h->side2[g]) != hipSuccess) return CSDO_EDEVICE;
+    HIP_OK(hipEventRecord(h->g_end2[g], h->side2[g]), CSDO_EDEVICE);
+    HIP_OK(hipStreamWaitEvent(s, h->g_end2[g], 0), CSDO_EDEVICE);
   }
   for (int g = 1; g < ng; ++g) HIP_OK(hipStreamWaitEvent(s, h->g_end[g], 0), CSDO_EDEVICE);   // join
   HIP_OK(hipEventRecord(h->ev1, s), CSDO_EDEVICE);
@@ -245,6 +297,10 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   for (int g = 0; g < ng; ++g) {
     HIP_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end[g]), CSDO_EDEVICE);
     h->groups[g].seconds = (double)ms * 1e-3;
+    if (h->groups[g].elastic > 0) {   // the group is done when both of its launches are
+      HIP_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end2[g]), CSDO_EDEVICE);
+      h->groups[g].seconds = std::max(h->groups[g].seconds, (double)ms * 1e-3);
+    }
   }
   HIP_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1), CSDO_EDEVICE);
   h->last_kernel_s = (double)ms * 1e-3;

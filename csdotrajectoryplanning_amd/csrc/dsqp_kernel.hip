@@ -12,7 +12,7 @@
 namespace csdo {
 
 template <int BLOCK, int MODE, bool SPLIT>
-hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, hipStream_t stream);   // dsqp_variant.hip
+hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream);   // dsqp_variant.hip
 
 __global__ void box_kernel(const double* __restrict__ pts, int n, const double* __restrict__ obs_aos, int n_obs,
                            double dimx, double dimy, double rv, double* __restrict__ boxes,
@@ -42,7 +42,7 @@ size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode) {
          sizeof(double);
 }
 
-constexpr size_t LDS_CAP = 160 * 1024;
+constexpr size_t LDS_CAP = 160 * 1024 - 64;   // 160 KB per workgroup minus the kernel's static LDS (queue slot)
 
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode) {
   // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024
@@ -54,16 +54,16 @@ int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode) {
   return block;
 }
 
-hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, hipStream_t stream) {
-  if (g.count <= 0) return hipSuccess;
+hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream) {
+  if (g.count <= 0 || workgroups <= 0) return hipSuccess;
   if (g.lds_bytes > LDS_CAP) return hipErrorInvalidValue;
   switch (g.block * 10 + g.mode) {
-    case 2560: return launch_variant<256, 0, true>(B, g, stream);
-    case 2562: return launch_variant<256, 2, true>(B, g, stream);
-    case 5120: return launch_variant<512, 0, true>(B, g, stream);
-    case 5121: return launch_variant<512, 1, true>(B, g, stream);
-    case 5122: return launch_variant<512, 2, true>(B, g, stream);
-    case 10242: return launch_variant<1024, 2, true>(B, g, stream);
+    case 2560: return launch_variant<256, 0, true>(B, g, workgroups, stream);
+    case 2562: return launch_variant<256, 2, true>(B, g, workgroups, stream);
+    case 5120: return launch_variant<512, 0, true>(B, g, workgroups, stream);
+    case 5121: return launch_variant<512, 1, true>(B, g, workgroups, stream);
+    case 5122: return launch_variant<512, 2, true>(B, g, workgroups, stream);
+    case 10242: return launch_variant<1024, 2, true>(B, g, workgroups, stream);
   }
   return hipErrorInvalidValue;
 }

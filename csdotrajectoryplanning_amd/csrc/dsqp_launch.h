@@ -14,11 +14,15 @@ struct LaunchGroup {
   int max_nt = 0;
   size_t lds_bytes = 0;       // dynamic LDS of the launch: the largest working set among the group's agents
   double seconds = 0.0;       // duration of the last launch (HIP events on the group's stream)
+  int* queue = nullptr;       // device counter of the group's agent queue (persistent workgroups)
+  int primary = 0, elastic = 0;   // workgroups of the first launch (the group's share of the CUs) and of the second one
 };
 size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode);   // LDS working set of one agent
 // kernel class of one agent: returns the workgroup size and sets the residency mode
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode);
-hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, hipStream_t stream);
+// Launches `workgroups` persistent workgroups that drain the group's queue (g.queue must have been zeroed on a stream
+// this launch is ordered after); several launches may share one queue.
+hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream);
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,
                         double* boxes, int* status, hipStream_t stream);
 }  // namespace csdo

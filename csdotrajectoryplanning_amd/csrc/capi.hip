@@ -209,7 +209,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
   // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
   {
-    const double mode_cost[3] = {1.0, 1.7, 2.5};
+    const double mode_cost[3] = {1.0, 1.45, 2.5};
     std::vector<double> work(h->groups.size(), 0.0);
     double total = 0.0;
     for (size_t g = 0; g < h->groups.size(); ++g) {
@@ -224,7 +224,9 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
       int n = (g + 1 == h->groups.size()) ? left : (int)std::lround(h->n_cu * work[g] / std::max(total, 1e-30));
       n = std::max(1, std::min(n, std::min(cap, std::max(left, 1))));
       G.primary = n;
-      G.elastic = cap - n;
+      // (the first group is the one whose agents run longest: its share is sized for them and it hands its CUs over as
+      // its queue drains; a second launch of it was observed to take CUs ahead of the later groups' first launches)
+      G.elastic = (g == 0 && h->groups.size() > 1) ? 0 : cap - n;
       left -= n;
     }
   }

@@ -126,7 +126,8 @@ int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
 double csdo_dsqp_last_kernel_seconds(csdo_handle h);
 /* How the uploaded batch is launched: agents are grouped by kernel class (workgroup size by horizon; LDS residency by
  * working set: 0 = coupling blocks, pivot inverses and bounds all in LDS, 1 = pivot inverses and bounds read from the
- * L2-resident workspace, 2 = only the exchange vectors in LDS) and the groups run concurrently.  Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
+ * L2-resident workspace, 2 = only the exchange vectors in LDS); every group is a set of persistent workgroups that take
+ * its agents off a queue ordered heaviest first, and the groups run concurrently.  Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
  * the duration of the group's kernel in the last csdo_dsqp_run.  No reference counterpart (the reference loops over
  * agents serially, sqp/dsqp_solver.cc:1198-1205). */
 typedef struct csdo_launch_group {

@@ -24,6 +24,5 @@ for label, sel in (("all agents", it >= 0), ("short agents (< 1000 iterations)",
     print("%s: %d agents, %d ADMM iterations, %d SQP iterations, %.1f ms of CU time (%.1f us per iteration, %.2f ms per SQP iteration)" % (
         label, sel.sum(), it[sel].sum(), sq[sel].sum(), tk[sel].sum() * 1e-5, tk[sel].sum() * 1e-2 / max(it[sel].sum(), 1), tk[sel].sum() * 1e-5 / max(sq[sel].sum(), 1)))
     print("   " + "  ".join("%s %.1f%%" % (n, 100.0 * p[i] / tot) for i, n in enumerate(NAMES[:15])))
-    f = ph[sel][:, 24:32].sum(0).astype(float)
-    print("   factor sub-phases, cycles per SQP iteration: " + "  ".join("%s %.0fk" % (n, f[i] / max(sq[sel].sum(), 1) / 1e3) for i, n in enumerate(["assemble", "eliminate", "absorb", "tail assemble", "gauss-jordan"])))
+
     print("   cycles per SQP iteration: " + "  ".join("%s %.0fk" % (NAMES[i], p[i] / max(sq[sel].sum(), 1) / 1e3) for i in (1, 2, 3, 4, 5, 10, 11, 12)))

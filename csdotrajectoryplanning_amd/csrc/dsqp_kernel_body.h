@@ -35,6 +35,13 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
     sh.carry2 = sh.er;
     rest = sh.er + 38 * st;
   } else if constexpr (MODE == 1) {
+    sh.lohi = nullptr;
+    sh.sinvs = rest;
+    sh.red = sh.sinvs;
+    sh.er = sh.sinvs + 22 * st;
+    sh.carry2 = sh.er;
+    rest = sh.er + 38 * st;
+  } else if constexpr (MODE == 2) {
     sh.lohi = sh.sinvs = nullptr;
     sh.er = rest;
     sh.red = sh.er;
@@ -50,7 +57,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   sh.bcast = sh.obs + 3 * n_obs;
   sh.tvec = sh.bcast + 32;
   sh.tinv = sh.tvec + 2 * TAIL_N;
-  sh.pc = MODE == 2 ? (B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes) : (sh.tinv + TAIL_N * 38);
+  sh.pc = MODE == 3 ? (B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes) : (sh.tinv + TAIL_N * 38);
   double* fac_global = B.fac_ws + ad_fac_off;
   sh.facE = fac_global;
   sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;

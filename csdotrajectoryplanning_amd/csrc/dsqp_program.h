@@ -264,7 +264,7 @@ struct Shm {
   double* bcast;    // [32] block-wide results
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
   double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
-  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in MODE 2)
+  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in MODE 3)
   int stride;
 };
 
@@ -279,7 +279,7 @@ struct AgentCtx {
 };
 
 // inter-vehicle row workspace: SoA by field, [field][4K] per agent (the 4 rows of a plane are contiguous)
-enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };   // then [3K] plane shares (MODE 2)
+enum { R_Y = 0, R_Z = 1, R_DY = 2, R_U = 3, R_E = 4, R_CA = 5, R_CB = 6, R_CY = 7 };   // then [3K] plane shares (MODE 3)
 
 // =========================================================================================================
 // Block-wide reductions.  Partials are stored per lane in sh.pl/sh.pr (12 slots); after a barrier the first wave
@@ -669,9 +669,10 @@ CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
 }
 
 // MODE: what an ADMM block keeps in LDS beside the 6-vectors, chosen per agent by its working set (dsqp_kernel.hip):
-//   0  coupling blocks E_r, pivot inverses, bounds and per-plane rhs shares      (94 doubles per timestep)
-//   1  E_r and the plane shares; pivot inverses and bounds are read from the L2-resident workspace   (50)
-//   2  only the 6-vectors and the reduction scratch: horizons beyond 256                             (30)
+//   0  coupling blocks E_r, pivot inverses, bounds and per-plane rhs shares                          (94 doubles per timestep)
+//   1  E_r, pivot inverses and the plane shares; the bounds are read from the L2-resident workspace  (72)
+//   2  E_r and the plane shares; pivot inverses and bounds from the workspace                        (50)
+//   3  only the 6-vectors and the reduction scratch: horizons beyond 256                             (30)
 template <int ROLE, int MODE, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out);

@@ -14,8 +14,8 @@ namespace csdo {
 #define SX(k, t) (sh.facX + (size_t)(k) * (size_t)sh.stride)[(unsigned)(t)]
 #define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
 // E_r of node t: LDS copy, or the workspace copy for long horizons
-#define ER(k, t) (MODE == 2 ? FE(36 + (k), t) : SH(er, k, t))
-#define SINV(k, t) (MODE != 0 ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
+#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : SH(er, k, t))
+#define SINV(k, t) (MODE >= 2 ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
 #define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 #define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 
@@ -211,7 +211,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           spd_inverse6(Ain, Sinv);
         }
         CSDO_FOR(k, 21, { WS(W_SINV + k, t) = Sinv[k]; });
-        if constexpr (MODE != 2) {
+        if constexpr (MODE != 3) {
           // Register-lean order: the 6x6 products T = Sinv Rl and V = Sinv Rr' are parked in this lane's (idle) E_r slot
           // of LDS as they are produced and read back column by column, so that one 6x6 operand, the pivot inverse and a
           // handful of accumulators are all that is live (the all-register version below spills, and a spilled double
@@ -1202,10 +1202,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_SLANES(t) {  // load the solver-lane cache and the inter-row share of the first rhs
         SolvRegs& V = CSDO_SS(t);
-        if constexpr (MODE == 0) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
+        if constexpr (MODE <= 1) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
         CSDO_FOR(k, 36, {
           V.el[k] = FE(k, t);
-          if constexpr (MODE != 2) SH(er, k, t) = FE(36 + k, t);
+          if constexpr (MODE != 3) SH(er, k, t) = FE(36 + k, t);
         });
       }
       CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, l, nthr, rho); }
@@ -1246,6 +1246,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #endif
         CSDO_LANES_HOT(t) {
           LaneState& S = CSDO_LS(t);
+          // modes >= 1: the 22 bounds of the home rows come from the workspace; one batch of loads in front of everything
+          // else of the update (a load per row inside the loop below costs an L2 round trip each)
+          double bnd[22];
+          if constexpr (MODE != 0) {
+            CSDO_FOR(k, 13, { bnd[k] = WS(W_LO + k, t); });
+            CSDO_FOR(k, 6, { bnd[13 + k] = WS(W_HI + 7 + k, t); });
+            CSDO_FOR(k, 3, { bnd[19 + k] = WS(W_HI + 13 + k, t); });
+          }
           double xt[6], xn[4] = {0, 0, 0, 0};
           CSDO_FOR(k, 6, { xt[k] = SH(vec, k, t); });
           if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
@@ -1260,19 +1268,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               const double rinv = rho_row<i>(S, rinv_in, rinv_eq);   // = 1.0 / rh (rho_inv_vec of OSQP)
               const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
               double lo_i, hi_i;
-              if constexpr (MODE != 0) {
-                lo_i = WS(W_LO + i, t);
-                hi_i = WS(W_HI + i, t);
-              } else {
-                if constexpr (i < 7) lo_i = hi_i = SH(lohi, i, t);
-                if constexpr (i >= 7 && i < 13) {
-                  lo_i = SH(lohi, i, t);
-                  hi_i = SH(lohi, i + 6, t);
-                }
-                if constexpr (i >= 13) {
-                  hi_i = SH(lohi, i + 6, t);
-                  lo_i = -hi_i;
-                }
+              // bounds in the packed order of Shm::lohi: from LDS, or (modes >= 1) from the batch fetched above
+              if constexpr (i < 7) lo_i = hi_i = (MODE != 0) ? bnd[i] : SH(lohi, i, t);
+              if constexpr (i >= 7 && i < 13) {
+                lo_i = (MODE != 0) ? bnd[i] : SH(lohi, i, t);
+                hi_i = (MODE != 0) ? bnd[i + 6] : SH(lohi, i + 6, t);
+              }
+              if constexpr (i >= 13) {
+                hi_i = (MODE != 0) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                lo_i = -hi_i;
               }
               const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], lo_i), hi_i);
               const double d = rh * (zr - zn);

@@ -125,15 +125,15 @@ int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
 /* Device time of the last csdo_dsqp_run in seconds (HIP events on the launch stream) and the kernel's own name. */
 double csdo_dsqp_last_kernel_seconds(csdo_handle h);
 /* How the uploaded batch is launched: agents are grouped by kernel class (workgroup size by horizon; LDS residency by
- * working set: 0 = coupling blocks, pivot inverses and bounds all in LDS, 1 = pivot inverses and bounds read from the
- * L2-resident workspace, 2 = only the exchange vectors in LDS); every group is a set of persistent workgroups that take
+ * working set: 0 = coupling blocks, pivot inverses and bounds all in LDS, 1 = bounds read from the L2-resident workspace,
+ * 2 = pivot inverses too, 3 = only the exchange vectors in LDS); every group is a set of persistent workgroups that take
  * its agents off a queue ordered heaviest first, and the groups run concurrently.  Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
  * the duration of the group's kernel in the last csdo_dsqp_run.  No reference counterpart (the reference loops over
  * agents serially, sqp/dsqp_solver.cc:1198-1205). */
 typedef struct csdo_launch_group {
   int32_t n_agents;
   int32_t threads;             /* per workgroup: 256, 512 or 1024 */
-  int32_t residency_mode;      /* 0, 1 or 2, see above */
+  int32_t residency_mode;      /* 0 .. 3, see above */
   int32_t max_nt;
   int64_t lds_bytes;
   double seconds;

@@ -13,7 +13,7 @@ using namespace csdo;
 
 // mode: LDS residency of the ADMM blocks (agent_program in dsqp_program.h); all three give identical results
 extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode) {
-  if (mode < 0 || mode > 2) return CSDO_EINVAL;
+  if (mode < 0 || mode > 3) return CSDO_EINVAL;
   HostBatch hb;
   const int rc = pack_worlds(worlds, n_worlds, hb);
   if (rc != CSDO_OK) return rc;
@@ -63,11 +63,14 @@ extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_w
     sh.tinv = sh.tvec + 2 * TAIL_N;
     sh.pc = sh.tinv + TAIL_N * 38;
     std::vector<double> pc_ws;
-    if (mode == 1) {            // no bounds / pivot inverses in LDS, reductions and hand-over in the E_r region
+    if (mode == 1) {            // as dsqp_kernel_body.h: no bounds in LDS, reductions over the pivot-inverse region
+      sh.lohi = nullptr;
+      sh.red = sh.sinvs;
+    } else if (mode == 2) {     // no bounds / pivot inverses in LDS, reductions and hand-over in the E_r region
       sh.lohi = sh.sinvs = nullptr;
       sh.red = sh.er;
       sh.carry2 = sh.er + 12 * st;
-    } else if (mode == 2) {     // only the 6-vectors, the hand-over and the reduction scratch
+    } else if (mode == 3) {     // only the 6-vectors, the hand-over and the reduction scratch
       sh.carry2 = sh.lohi;
       sh.red = sh.carry2 + 6 * st;
       sh.lohi = sh.sinvs = sh.er = nullptr;
@@ -82,7 +85,8 @@ extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_w
     ProgramOut po{};
     if (mode == 0) agent_program<ROLE_BOTH, 0>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 1) agent_program<ROLE_BOTH, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-    else agent_program<ROLE_BOTH, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else if (mode == 2) agent_program<ROLE_BOTH, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else agent_program<ROLE_BOTH, 3>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     sqp[a] = po.sqp_iters;
     admm[a] = po.admm_iters;
     stat[a] = po.last_status;

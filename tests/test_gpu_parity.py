@@ -85,14 +85,14 @@ def test_gpu_is_deterministic_and_handle_is_reusable(gpu_handle, veh_parm):
 
 
 def test_gpu_lds_residency_modes_are_bit_identical(gpu_handle, veh_parm):
-    """Agents whose working set exceeds LDS read pivot inverses / bounds (mode 1) or also the coupling blocks (mode 2)
-    from the workspace: same doubles, same arithmetic, so bit-identical results; mixed batches launch concurrently."""
+    """Agents whose working set exceeds LDS read the bounds (mode 1), also the pivot inverses (mode 2) or also the coupling
+    blocks (mode 3) from the workspace: same doubles, same arithmetic, so bit-identical results."""
     veh, parm = veh_parm
     w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     w2, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)      # Nt = 169: 512-thread class
     ref = gpu_handle.solve_batch([w1, w2])
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             gpu_handle.set_min_residency_mode(mode)
             got = gpu_handle.solve_batch([w1, w2])
             groups = gpu_handle.launch_groups()

@@ -55,12 +55,12 @@ def test_batch_of_worlds_equals_separate_solves(emu, veh_parm):
 
 
 def test_lds_residency_modes_are_bit_identical(emu, veh_parm):
-    """The three LDS residency modes of the ADMM block (agent_program MODE 0/1/2: which operands come from LDS and which
+    """The four LDS residency modes of the ADMM block (agent_program MODE 0..3: which operands come from LDS and which
     from the workspace) only change where the same doubles are read from."""
     veh, parm = veh_parm
     world, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     ref = emu.solve(world, 0)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         got = emu.solve(world, mode)
         assert np.array_equal(ref.solutions, got.solutions) and np.array_equal(ref.corridors, got.corridors)
         assert np.array_equal(ref.admm_iters, got.admm_iters) and np.array_equal(ref.last_status, got.last_status)

@@ -209,7 +209,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
   // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
   {
-    const double mode_cost[4] = {1.0, 1.2, 1.6, 2.5};
+    const double mode_cost[4] = {1.0, 1.0, 1.6, 2.5};
     std::vector<double> work(h->groups.size(), 0.0);
     double total = 0.0;
     for (size_t g = 0; g < h->groups.size(); ++g) {

@@ -54,5 +54,10 @@ if __name__ == '__main__':
         len(ids), len(gaps), np.median(gaps), gaps.mean(), np.percentile(gaps, 90), gaps.max(), gaps.sum() / 256))
     per_x = [(int(x), int((((hw >> 32) & 0xf) == x).sum()), float(end[((hw >> 32) & 0xf) == x].max())) for x in np.unique((hw >> 32) & 0xf)]
     print('per XCC: (id, workgroups, last end ms): ' + ' '.join('(%d,%d,%.0f)' % t for t in per_x))
+    K = np.concatenate([w.plane_off[1:] - w.plane_off[:-1] for w in worlds])
+    NT = np.concatenate([np.full(w.Na, w.Nt) for w in worlds])
+    IT = np.concatenate([s_.admm_iters for s_ in sols]); SQ = np.concatenate([s_.sqp_iters for s_ in sols])
+    m = np.where((start > 0.75 * end.max()) & (dur > 12))[0]
+    print('late and long (start, dur, K, Nt, admm, sqp): ' + ' '.join('(%.0f,%.0f,%d,%d,%d,%d)' % (start[i], dur[i], K[i], NT[i], IT[i], SQ[i]) for i in m[:16]))
     late = np.argsort(-end)[:8]
     print('last to finish: ' + ', '.join('g%d start %.0f dur %.0f' % (of[i], start[i], dur[i]) for i in late))

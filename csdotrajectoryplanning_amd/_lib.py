@@ -43,6 +43,7 @@ def lib():
         L.csdo_dsqp_download.argtypes = [H, C.POINTER(abi.Result), C.c_int32]
         L.csdo_dsqp_last_kernel_seconds.argtypes = [H]
         L.csdo_dsqp_last_kernel_seconds.restype = C.c_double
+        L.csdo_dsqp_last_transfer_seconds.argtypes = [H, C.POINTER(C.c_double * 5)]
         L.csdo_dsqp_launch_groups.argtypes = [H, C.POINTER(abi.LaunchGroup), C.c_int32]
         L.csdo_dsqp_launch_groups.restype = C.c_int32
         L.csdo_dsqp_set_min_residency_mode.argtypes = [H, C.c_int32]

@@ -67,9 +67,20 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
   hb.world_first_agent.push_back(0);
   for (int w = 0; w < n_worlds; ++w) {
     const csdo_problem& W = worlds[w];
-    if (W.Na < 1 || W.Nt < 2 || !W.x0_bar || !W.plane_off || (W.n_obs > 0 && !W.obstacles)) return CSDO_EINVAL;
+    if (W.Na < 1 || W.Nt < 2 || W.n_obs < 0 || !W.x0_bar || !W.plane_off || (W.n_obs > 0 && !W.obstacles))
+      return CSDO_EINVAL;
     if (W.Nt > CSDO_MAX_NT) return CSDO_ELIMIT;
+    if (W.plane_off[0] != 0) return CSDO_EINVAL;
+    for (int a = 0; a < W.Na; ++a)
+      if (W.plane_off[a + 1] < W.plane_off[a]) return CSDO_EINVAL;   // CSR offsets must be monotone
     if (W.plane_off[W.Na] > 0 && !W.planes) return CSDO_EINVAL;
+    // One launch reads ONE parameter block (vehicle geometry + QpParm): every world of a batch must carry the values of
+    // worlds[0] (compared after the same normalisation make_params applies), otherwise CSDO_EINVAL - never a silent
+    // solve with the wrong dt / trust radius / iteration caps.
+    if (w > 0) {
+      const SolverParams pw = make_params(W.veh, W.parm);
+      if (std::memcmp(&pw, &hb.prm, sizeof(SolverParams)) != 0) return CSDO_EINVAL;
+    }
     WorldDesc wd{};
     wd.dimx = W.dimx;
     wd.dimy = W.dimy;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/csdo_dsqp.h"
@@ -40,6 +41,30 @@ struct DevBuf {
   }
 };
 
+// Page-locked host staging: H2D / D2H copies from pageable memory run at a fraction of the PCIe rate and serialise
+// with the host; the packed batch is staged here once and every array goes out as one asynchronous copy.
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap && p) return CSDO_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 8;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return CSDO_ENOMEM;
+    cap = want;
+    return CSDO_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 }  // namespace
 
 struct csdo_handle_s {
@@ -61,9 +86,8 @@ struct csdo_handle_s {
   DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d, queues;
   DevBuf box_pts, box_obs, box_out, box_status;
   DevBuf prof;
-  std::vector<double> h_sol, h_corr;
-  std::vector<int32_t> h_sqp, h_admm, h_stat, h_legal;
-  std::vector<int64_t> h_ticks;
+  PinnedBuf stage_up, stage_down;   // page-locked staging of the packed inputs / outputs
+  double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
   DeviceBatch dev{};
 };
 
@@ -164,8 +188,10 @@ void csdo_dsqp_destroy(csdo_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
                     &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->queues, &h->box_pts,
-                    &h->box_obs, &h->box_out, &h->box_status})
+                    &h->box_obs, &h->box_out, &h->box_status, &h->prof})
     b->release();
+  h->stage_up.release();
+  h->stage_down.release();
   for (hipStream_t s : h->side) (void)hipStreamDestroy(s);
   for (hipEvent_t e : h->g_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_end) (void)hipEventDestroy(e);
@@ -182,25 +208,59 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   if (!h) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   h->uploaded = false;
+  const double t0 = now_s();
   int rc = pack_worlds(worlds, n_worlds, h->hb);
   if (rc != CSDO_OK) return rc;
   HostBatch& hb = h->hb;
   const size_t Na = hb.agents.size();
-#define UP(buf, vec)                                                                                         \
-  do {                                                                                                       \
-    const size_t bytes = (vec).size() * sizeof((vec)[0]);                                                    \
-    if ((rc = h->buf.ensure(bytes)) != CSDO_OK) return rc;                                                   \
-    if (bytes) HIP_OK(hipMemcpyAsync(h->buf.p, (vec).data(), bytes, hipMemcpyHostToDevice, h->stream), CSDO_EDEVICE); \
-  } while (0)
-  UP(agents, hb.agents);
-  UP(worlds, hb.worlds);
-  UP(x0, hb.x0);
-  UP(planes, hb.planes);
-  UP(tstart, hb.tstart);
-  UP(obstacles, hb.obstacles);
   if ((rc = build_groups(h)) != CSDO_OK) return rc;
-  UP(order_d, h->order);
-#undef UP
+  for (const LaunchGroup& g : h->groups)
+    if (g.lds_bytes > dsqp_lds_capacity()) return CSDO_ELIMIT;   // e.g. more obstacles than fit beside the exchange vectors
+  const double t1 = now_s();
+  // stage everything in one page-locked arena (256-byte aligned slots), then one asynchronous copy per array
+  struct Item { DevBuf* buf; const void* src; size_t bytes; size_t off; };
+  Item items[] = {{&h->agents, hb.agents.data(), hb.agents.size() * sizeof(AgentDesc), 0},
+                  {&h->worlds, hb.worlds.data(), hb.worlds.size() * sizeof(WorldDesc), 0},
+                  {&h->x0, hb.x0.data(), hb.x0.size() * sizeof(double), 0},
+                  {&h->planes, hb.planes.data(), hb.planes.size() * sizeof(PlaneDev), 0},
+                  {&h->tstart, hb.tstart.data(), hb.tstart.size() * sizeof(int32_t), 0},
+                  {&h->obstacles, hb.obstacles.data(), hb.obstacles.size() * sizeof(double), 0},
+                  {&h->order_d, h->order.data(), h->order.size() * sizeof(int32_t), 0}};
+  size_t total = 0;
+  for (Item& it : items) {
+    it.off = total;
+    total += (it.bytes + 255) & ~(size_t)255;
+  }
+  if ((rc = h->stage_up.ensure(total)) != CSDO_OK) return rc;
+  {
+    // the big arrays (planes, x0) are copied by a few threads: a single memcpy stream does not reach the DRAM rate
+    std::vector<std::thread> pool;
+    for (Item& it : items) {
+      if (!it.bytes) continue;
+      char* dst = (char*)h->stage_up.p + it.off;
+      const char* src = (const char*)it.src;
+      const size_t chunk = (size_t)4 << 20;
+      if (it.bytes <= chunk) {
+        std::memcpy(dst, src, it.bytes);
+      } else {
+        const int parts = (int)std::min<size_t>(8, (it.bytes + chunk - 1) / chunk);
+        const size_t per = ((it.bytes + parts - 1) / parts + 63) & ~(size_t)63;
+        for (int k = 0; k < parts; ++k) {
+          const size_t lo = (size_t)k * per, hi = std::min(it.bytes, lo + per);
+          if (lo < hi) pool.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+        }
+      }
+    }
+    for (auto& t : pool) t.join();
+  }
+  const double t2 = now_s();
+  for (Item& it : items) {
+    if ((rc = it.buf->ensure(it.bytes)) != CSDO_OK) return rc;
+    if (it.bytes)
+      HIP_OK(hipMemcpyAsync(it.buf->p, (char*)h->stage_up.p + it.off, it.bytes, hipMemcpyHostToDevice, h->stream), CSDO_EDEVICE);
+  }
+  h->t_pack = t1 - t0;
+  h->t_stage = t2 - t1;
   if ((rc = h->queues.ensure(h->groups.size() * 64)) != CSDO_OK) return rc;   // one counter per group, a cache line apart
   for (size_t g = 0; g < h->groups.size(); ++g) {
     h->groups[g].queue = (int*)((char*)h->queues.p + g * 64);
@@ -265,6 +325,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
 #endif
   B.prm = hb.prm;
   HIP_OK(hipStreamSynchronize(h->stream), CSDO_EDEVICE);
+  h->t_h2d = now_s() - t2;
   h->n_worlds = n_worlds;
   h->uploaded = true;
   return CSDO_OK;
@@ -273,43 +334,62 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
 int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   if (!h || !h->uploaded) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  // after the fork an error must not leave side streams running behind the caller's back: drain the device first
+#define RUN_OK(expr)                      \
+  do {                                    \
+    if ((expr) != hipSuccess) {           \
+      (void)hipDeviceSynchronize();       \
+      return CSDO_EDEVICE;                \
+    }                                     \
+  } while (0)
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-  HIP_OK(hipEventRecord(h->ev0, s), CSDO_EDEVICE);
+  RUN_OK(hipEventRecord(h->ev0, s));
   const int ng = (int)h->groups.size();
   for (int g = 0; g < ng; ++g) {   // fork: every group starts when the caller's stream reaches this point
     hipStream_t gs = g == 0 ? s : h->side[g - 1];
-    if (g > 0) HIP_OK(hipStreamWaitEvent(gs, h->ev0, 0), CSDO_EDEVICE);
-    HIP_OK(hipEventRecord(h->g_begin[g], gs), CSDO_EDEVICE);
-    HIP_OK(hipMemsetAsync(h->groups[g].queue, 0, sizeof(int), gs), CSDO_EDEVICE);
-    HIP_OK(hipEventRecord(h->g_zeroed[g], gs), CSDO_EDEVICE);
-    if (launch_dsqp(h->dev, h->groups[g], h->groups[g].primary, gs) != hipSuccess) return CSDO_EDEVICE;
-    HIP_OK(hipEventRecord(h->g_end[g], gs), CSDO_EDEVICE);
+    if (g > 0) RUN_OK(hipStreamWaitEvent(gs, h->ev0, 0));
+    RUN_OK(hipEventRecord(h->g_begin[g], gs));
+    RUN_OK(hipMemsetAsync(h->groups[g].queue, 0, sizeof(int), gs));
+    RUN_OK(hipEventRecord(h->g_zeroed[g], gs));
+    RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].primary, gs));
+    RUN_OK(hipEventRecord(h->g_end[g], gs));
   }
   for (int g = 0; g < ng; ++g) {   // second launches: same queues, workgroups that start on CUs other groups release
     if (h->groups[g].elastic <= 0) continue;
-    HIP_OK(hipStreamWaitEvent(h->side2[g], h->g_zeroed[g], 0), CSDO_EDEVICE);
-    if (launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, h->side2[g]) != hipSuccess) return CSDO_EDEVICE;
-    HIP_OK(hipEventRecord(h->g_end2[g], h->side2[g]), CSDO_EDEVICE);
-    HIP_OK(hipStreamWaitEvent(s, h->g_end2[g], 0), CSDO_EDEVICE);
+    RUN_OK(hipStreamWaitEvent(h->side2[g], h->g_zeroed[g], 0));
+    RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, h->side2[g]));
+    RUN_OK(hipEventRecord(h->g_end2[g], h->side2[g]));
+    RUN_OK(hipStreamWaitEvent(s, h->g_end2[g], 0));
   }
-  for (int g = 1; g < ng; ++g) HIP_OK(hipStreamWaitEvent(s, h->g_end[g], 0), CSDO_EDEVICE);   // join
-  HIP_OK(hipEventRecord(h->ev1, s), CSDO_EDEVICE);
-  HIP_OK(hipEventSynchronize(h->ev1), CSDO_EDEVICE);
+  for (int g = 1; g < ng; ++g) RUN_OK(hipStreamWaitEvent(s, h->g_end[g], 0));   // join
+  RUN_OK(hipEventRecord(h->ev1, s));
+  RUN_OK(hipEventSynchronize(h->ev1));
   float ms = 0.f;
   for (int g = 0; g < ng; ++g) {
-    HIP_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end[g]), CSDO_EDEVICE);
+    RUN_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end[g]));
     h->groups[g].seconds = (double)ms * 1e-3;
     if (h->groups[g].elastic > 0) {   // the group is done when both of its launches are
-      HIP_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end2[g]), CSDO_EDEVICE);
+      RUN_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end2[g]));
       h->groups[g].seconds = std::max(h->groups[g].seconds, (double)ms * 1e-3);
     }
   }
-  HIP_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1), CSDO_EDEVICE);
+  RUN_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_kernel_s = (double)ms * 1e-3;
+#undef RUN_OK
   return CSDO_OK;
 }
 
 double csdo_dsqp_last_kernel_seconds(csdo_handle h) { return h ? h->last_kernel_s : 0.0; }
+
+int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]) {
+  if (!h || !out) return CSDO_EINVAL;
+  out[0] = h->t_pack;
+  out[1] = h->t_stage;
+  out[2] = h->t_h2d;
+  out[3] = h->t_d2h;
+  out[4] = h->t_unpack;
+  return CSDO_OK;
+}
 
 int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents) {
   if (!h || !h->uploaded || !group_of_agent || n_agents != (int32_t)h->order.size()) return CSDO_EINVAL;
@@ -350,29 +430,34 @@ int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   const HostBatch& hb = h->hb;
   const size_t Na = hb.agents.size();
-  h->h_sol.resize((size_t)hb.steps_total * 6);
-  h->h_corr.resize((size_t)hb.steps_total * 8);
-  h->h_sqp.resize(Na);
-  h->h_admm.resize(Na);
-  h->h_stat.resize(Na);
-  h->h_legal.resize(Na);
-  h->h_ticks.resize(Na);
+  const double t0 = now_s();
+  const size_t b_sol = (size_t)hb.steps_total * 6 * sizeof(double), b_corr = (size_t)hb.steps_total * 8 * sizeof(double);
+  const size_t b_i32 = (Na * sizeof(int32_t) + 255) & ~(size_t)255, b_i64 = Na * sizeof(int64_t);
+  const size_t o_corr = (b_sol + 255) & ~(size_t)255, o_sqp = o_corr + ((b_corr + 255) & ~(size_t)255);
+  const size_t o_admm = o_sqp + b_i32, o_stat = o_admm + b_i32, o_legal = o_stat + b_i32, o_ticks = o_legal + b_i32;
+  int rc;
+  if ((rc = h->stage_down.ensure(o_ticks + b_i64)) != CSDO_OK) return rc;
+  char* st = (char*)h->stage_down.p;
   hipStream_t s = h->stream;
-  HIP_OK(hipMemcpyAsync(h->h_sol.data(), h->sol.p, h->h_sol.size() * sizeof(double), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->h_corr.data(), h->corr.p, h->h_corr.size() * sizeof(double), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->h_sqp.data(), h->sqp.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->h_admm.data(), h->admm.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->h_stat.data(), h->stat.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->h_legal.data(), h->legal.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->h_ticks.data(), h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st, h->sol.p, b_sol, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st + o_corr, h->corr.p, b_corr, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st + o_sqp, h->sqp.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st + o_admm, h->admm.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st + o_stat, h->stat.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st + o_legal, h->legal.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(st + o_ticks, h->ticks.p, b_i64, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
   HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
-  unpack_results(hb, nullptr, n_worlds, h->h_sol.data(), h->h_corr.data(), h->h_sqp.data(), h->h_admm.data(),
-                 h->h_stat.data(), h->h_legal.data(), results);
+  const double t1 = now_s();
+  const int64_t* h_ticks = (const int64_t*)(st + o_ticks);
+  unpack_results(hb, nullptr, n_worlds, (const double*)st, (const double*)(st + o_corr), (const int32_t*)(st + o_sqp),
+                 (const int32_t*)(st + o_admm), (const int32_t*)(st + o_stat), (const int32_t*)(st + o_legal), results);
+  h->t_d2h = t1 - t0;
+  h->t_unpack = now_s() - t1;
   for (int w = 0; w < n_worlds; ++w) {
     int64_t mx = 0;
     for (int a = hb.world_first_agent[w]; a < hb.world_first_agent[w + 1]; ++a) {
-      mx = std::max(mx, h->h_ticks[a]);
-      if (results[w].agent_seconds) results[w].agent_seconds[a - hb.world_first_agent[w]] = (double)h->h_ticks[a] * 1e-8;
+      mx = std::max(mx, h_ticks[a]);
+      if (results[w].agent_seconds) results[w].agent_seconds[a - hb.world_first_agent[w]] = (double)h_ticks[a] * 1e-8;
     }
     results[w].t_max_individual = (double)mx * 1e-8;  // wall_clock64 ticks at 100 MHz
     results[w].t_device = h->last_kernel_s;

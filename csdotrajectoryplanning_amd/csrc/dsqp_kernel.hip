@@ -44,6 +44,7 @@ size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode) {
 }
 
 constexpr size_t LDS_CAP = 160 * 1024 - 64;   // 160 KB per workgroup minus the kernel's static LDS (queue slot)
+size_t dsqp_lds_capacity() { return LDS_CAP; }
 
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode) {
   // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024

@@ -18,6 +18,7 @@ struct LaunchGroup {
   int primary = 0, elastic = 0;   // workgroups of the first launch (the group's share of the CUs) and of the second one
 };
 size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode);   // LDS working set of one agent
+size_t dsqp_lds_capacity();                                        // dynamic LDS one workgroup may ask for
 // kernel class of one agent: returns the workgroup size and sets the residency mode
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode);
 // Launches `workgroups` persistent workgroups that drain the group's queue (g.queue must have been zeroed on a stream

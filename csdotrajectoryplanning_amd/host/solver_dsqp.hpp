@@ -1,7 +1,11 @@
 // solver_dsqp.hpp — header-only C++ mirror of the reference's `SolverDSQP` (sqp/dsqp_solver.h:24-47) on top of the C ABI
 // (include/csdo_dsqp.h).  Same constructor shape, same public members and getters, so csdo.cc keeps its call site
-// (csdo.cc:146-159); the types below are the reference's PODs restated (sqp/common.h:14-52, sqp/corridor.h:8-11,
-// sqp/inter_agent_cons.h:47-63, common/motion_planning.h:79-84).  Link with -lcsdo_hip.
+// (csdo.cc:146-159).  The constructor is a template over the caller's element types: it reads the FIELDS of whatever
+// OptimizeResult / InterPlane / Location / QpParm types it is handed (the reference's own
+// libMultiRobotPlanning structs, sqp/common.h:14-52, sqp/inter_agent_cons.h:47-63, common/motion_planning.h:79-84, pass
+// unchanged - no conversion, no typedef), and any iterable of obstacles (the reference passes an unordered_set).
+// tests/cpp/mirror_main.cc compiles this header against stand-ins shaped like the reference's structs.
+// Link with -lcsdo_hip.
 #pragma once
 #include <stdexcept>
 #include <string>
@@ -34,27 +38,28 @@ struct QpParm {
 
 class SolverDSQP {
  public:
-  // Any iterable of Location works for `obstacles` (the reference passes an unordered_set; order only matters when a
-  // point lies inside two inflated obstacles — this backend uses the iteration order it is given).
-  template <class ObstacleRange>
-  SolverDSQP(std::vector<std::vector<OptimizeResult>>& solutions,
-             const std::vector<std::vector<OptimizeResult>>& x0_bar,
-             const std::vector<std::vector<InterPlane>>& inter_planes, double dimx, double dimy,
-             const ObstacleRange& obstacles, const QpParm& param, int logger_level = 2, int device = 0,
+  // OptRes: fields x, y, yaw, v, steer, d_steer (sqp/common.h:14-22).  Plane: t, a_f2f .. c_r2r (inter_agent_cons.h:47-63).
+  // Parm: the QpParm fields (sqp/common.h:39-52).  ObstacleRange: any iterable whose elements have x, y, r (the reference
+  // passes an unordered_set<Location>; order only matters when a point lies inside two inflated obstacles - this backend
+  // uses the iteration order it is given).  The structs above are conveniences for callers that have no types of their own.
+  template <class OptRes, class Plane, class ObstacleRange, class Parm>
+  SolverDSQP(std::vector<std::vector<OptRes>>& solutions, const std::vector<std::vector<OptRes>>& x0_bar,
+             const std::vector<std::vector<Plane>>& inter_planes, double dimx, double dimy,
+             const ObstacleRange& obstacles, const Parm& param, int logger_level = 2, int device = 0,
              const csdo_vehicle* vehicle = nullptr) {
     const int Na = (int)x0_bar.size();
     const int Nt = Na ? (int)x0_bar[0].size() : 0;
     std::vector<double> x0((size_t)Na * Nt * 6), obs;
     for (int a = 0; a < Na; ++a)
       for (int t = 0; t < Nt; ++t) {
-        const OptimizeResult& r = x0_bar[a][t];
+        const OptRes& r = x0_bar[a][t];
         double* g = &x0[((size_t)a * Nt + t) * 6];
         g[0] = r.x; g[1] = r.y; g[2] = r.yaw; g[3] = r.steer; g[4] = r.v; g[5] = r.d_steer;
       }
     std::vector<int32_t> off(Na + 1, 0);
     std::vector<csdo_plane> planes;
     for (int a = 0; a < Na; ++a) {
-      for (const InterPlane& p : inter_planes[a]) {
+      for (const Plane& p : inter_planes[a]) {
         csdo_plane q{};
         q.t = p.t;
         const double c[12] = {p.a_f2f, p.b_f2f, p.c_f2f, p.a_f2r, p.b_f2r, p.c_f2r,
@@ -83,7 +88,7 @@ class SolverDSQP {
     P.parm.r_trust = param.r_trust;
     P.parm.max_omega = param.max_omega;
     P.parm.max_v = param.max_v;
-    P.parm.max_iter = param.max_iter;
+    P.parm.max_iter = (double)param.max_iter;
     P.parm.delta_solution_threshold = param.delta_solution_threshold;
     P.parm.max_violation = param.max_violation;
     P.parm.osqp_max_iter = param.osqp_max_iter;
@@ -108,12 +113,12 @@ class SolverDSQP {
     if (h) csdo_dsqp_destroy(h);
     if (rc != CSDO_OK) throw std::runtime_error("csdo_dsqp_solve failed with code " + std::to_string(rc));
 
-    solutions.assign(Na, std::vector<OptimizeResult>(Nt));
+    solutions.assign(Na, std::vector<OptRes>(Nt));
     corridors.assign(Na, std::vector<Corridor>(Nt));
     for (int a = 0; a < Na; ++a)
       for (int t = 0; t < Nt; ++t) {
         const double* s = &sol[((size_t)a * Nt + t) * 6];
-        OptimizeResult& r = solutions[a][t];
+        OptRes& r = solutions[a][t];
         r.x = s[0]; r.y = s[1]; r.yaw = s[2]; r.steer = s[3]; r.v = s[4]; r.d_steer = s[5];
         const double* c = &cor[((size_t)a * Nt + t) * 8];
         corridors[a][t] = Corridor{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};

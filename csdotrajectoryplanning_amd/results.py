@@ -158,3 +158,34 @@ def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0) -
             bad |= (k[..., 0] < 0) | (k[..., 0] > dimx) | (k[..., 1] < 0) | (k[..., 1] > dimy)
         out = int(bad.sum())
     return ValidationReport(veh_hits, obs_hits, out, first_v, first_o, clearance)
+
+
+def feasibility(world, solutions):
+    """Per-agent acceptance measures of a DO-phase result, independent of any solver: the kinematic and separating-plane
+    parts of the reference's own isFeasible (sqp/dsqp_solver.cc:292-420: mean-square bicycle-model residual, largest
+    plane violation with the exact disc centres) and the QP objective 1/2 sum (v_{k+1}-v_k)^2 + 1/2 sum w^2 (:163-197).
+    Returns dict(kin [Na], planes [Na], objective [Na]); isFeasible's thresholds are 1e-2 and 1e-1."""
+    sol = np.asarray(solutions, dtype=np.float64)
+    Na, Nt = sol.shape[:2]
+    P, V = world.parm, world.veh
+    x, y, yaw, st, v, w = (sol[..., k] for k in range(6))
+    r1 = x[:, :-1] + v[:, :-1] * np.cos(yaw[:, :-1]) * P.dt - x[:, 1:]
+    r2 = y[:, :-1] + v[:, :-1] * np.sin(yaw[:, :-1]) * P.dt - y[:, 1:]
+    r3 = yaw[:, :-1] + v[:, :-1] * np.tan(st[:, :-1]) / V.WB * P.dt - yaw[:, 1:]
+    r4 = st[:, :-1] + w[:, :-1] * P.dt - st[:, 1:]
+    kin = ((r1 ** 2).sum(1) + (r2 ** 2).sum(1) + (r3 ** 2).sum(1) + (r4 ** 2).sum(1)) / Nt
+    xf, yf = x + V.f2x * np.cos(yaw), y + V.f2x * np.sin(yaw)
+    xr, yr = x + V.r2x * np.cos(yaw), y + V.r2x * np.sin(yaw)
+    planes = np.zeros(Na)
+    po = world.plane_off
+    for a in range(Na):
+        pl = world.planes[po[a]:po[a + 1]]
+        if len(pl) == 0:
+            continue
+        t, c = pl["t"], pl["c"]
+        res = np.stack([c[:, 0] * xf[a, t] + c[:, 1] * yf[a, t] + c[:, 2], c[:, 3] * xf[a, t] + c[:, 4] * yf[a, t] + c[:, 5],
+                        c[:, 6] * xr[a, t] + c[:, 7] * yr[a, t] + c[:, 8], c[:, 9] * xr[a, t] + c[:, 10] * yr[a, t] + c[:, 11]])
+        planes[a] = max(0.0, float(res.max()))
+    vv, ww = v[:, :-1], w[:, :-1]
+    objective = 0.5 * ((vv[:, 1:] - vv[:, :-1]) ** 2).sum(1) + 0.5 * (ww ** 2).sum(1)
+    return dict(kin=kin, planes=planes, objective=objective)

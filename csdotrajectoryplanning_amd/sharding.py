@@ -21,6 +21,56 @@ def shard_world(world, rank, world_size):
     return (world.subset(lo, hi) if hi > lo else None), (lo, hi)
 
 
+def shard_batch_plan(world_sizes, rank, world_size):
+    """Contiguous block of the batch's agents (worlds concatenated in order) owned by `rank`: a list of
+    (world index, lo, hi) with agents [lo, hi) of that world; only worlds that overlap the block appear."""
+    total = int(sum(world_sizes))
+    lo, hi = shard_bounds(total, world_size)[rank]
+    plan, first = [], 0
+    for w, n in enumerate(world_sizes):
+        a, b = max(lo, first), min(hi, first + n)
+        if b > a:
+            plan.append((w, a - first, b - first))
+        first += n
+    return plan
+
+
+def shard_batch(worlds, rank, world_size):
+    """This rank's share of a batch of worlds: whole worlds where the block covers them, World.subset otherwise."""
+    out = []
+    for w, lo, hi in shard_batch_plan([x.Na for x in worlds], rank, world_size):
+        out.append(worlds[w] if (lo == 0 and hi == worlds[w].Na) else worlds[w].subset(lo, hi))
+    return out
+
+
+class FlatGather:
+    """The step-end collective of a sharded batch: all_gather of per-rank flat fp64 buffers of different lengths (a rank's
+    packed trajectories, [sum Nt][6]) with preallocated buffers - padded to the longest, one all_gather_into_tensor per
+    call, on whatever stream is current.  `local` tensors live where `device` says (device memory on the GPU path: the
+    collective reads the solver's own output buffer through a device-to-device copy, no host hop)."""
+
+    def __init__(self, n_local, dist, device):
+        import torch
+        self.dist, self.n_local = dist, int(n_local)
+        ws = dist.get_world_size()
+        lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(ws)]
+        dist.all_gather(lens, torch.tensor([self.n_local], dtype=torch.int64, device=device))
+        self.lengths = [int(x) for x in lens]
+        self.n_max = max(self.lengths)
+        self.send = torch.zeros(self.n_max, dtype=torch.float64, device=device)
+        self.out = torch.empty(ws * self.n_max, dtype=torch.float64, device=device)
+
+    def gather(self, local):
+        self.send[:self.n_local].copy_(local[:self.n_local])
+        self.dist.all_gather_into_tensor(self.out, self.send)
+        return self.out.view(len(self.lengths), self.n_max)
+
+    def parts(self):
+        """The ranks' buffers without padding, in rank order (views into the gathered tensor)."""
+        v = self.out.view(len(self.lengths), self.n_max)
+        return [v[r, :n] for r, n in enumerate(self.lengths)]
+
+
 def gather_solutions(local_solutions, n_total, Nt, rank, world_size, dist, device=None):
     """all_gather of per-rank [Na_r, Nt, 6] blocks into [n_total, Nt, 6] on every rank.  Blocks are padded to the
     largest shard so one all_gather_into_tensor moves everything (payload: 50 agents x 169 steps x 6 x 8 B = 0.4 MB)."""

@@ -57,6 +57,12 @@ class DsqpHandle:
         check(lib().csdo_dsqp_run(self._h, C.c_void_p(stream) if stream else None), "csdo_dsqp_run")
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
 
+    def transfer_seconds(self):
+        """Host seconds of the last upload / download: dict(pack, stage, h2d, d2h, unpack)."""
+        out = (C.c_double * 5)()
+        check(lib().csdo_dsqp_last_transfer_seconds(self._h, C.byref(out)), "csdo_dsqp_last_transfer_seconds")
+        return dict(zip(("pack", "stage", "h2d", "d2h", "unpack"), [float(v) for v in out]))
+
     def set_min_residency_mode(self, mode):
         check(lib().csdo_dsqp_set_min_residency_mode(self._h, int(mode)), "csdo_dsqp_set_min_residency_mode")
 

@@ -13,6 +13,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INSTANCE_DIR = os.path.join(_ROOT, "tests", "golden", "instances")
 
 MAP50_AGENTS25 = "map_50by50_obst25_agents25_ex0.yaml"
+MAP50_AGENTS25_SET = "map_50by50_obst25_agents25_ex{}.yaml"
 MAP100_AGENTS50 = "map_100by100_obst50_agents50_ex{}.yaml"
 
 
@@ -40,3 +41,84 @@ MAP100_SET_SIZE = 60   # benchmark/map100by100/agents50/obstacle holds ex0 .. ex
 def map100_world(k, veh=None, parm=None, seed_offset=0):
     """Instance ex{k} of the map100by100/agents50/obstacle set; the front-end stand-in is seeded with k + seed_offset."""
     return build_world(MAP100_AGENTS50.format(k), seed=k + seed_offset, veh=veh, parm=parm)
+
+
+MAP50_SET_SIZE = 60    # benchmark/map50by50/agents25/obstacle holds ex0 .. ex59
+
+
+def map50_world(k, veh=None, parm=None, seed_offset=0):
+    """Instance ex{k} of the map50by50/agents25/obstacle set (BASELINE.json configs[1]); seed k + seed_offset.
+    (ex0 with seed 0 is the world the single-instance fixtures and tests use.)"""
+    return build_world(MAP50_AGENTS25_SET.format(k), seed=k + seed_offset, veh=veh, parm=parm)
+
+
+SYNTH1024_AGENTS = 1024
+
+
+def synthetic_1024(veh=None, parm=None, seed_offset=0, n_agents=SYNTH1024_AGENTS):
+    """BASELINE.json configs[4], as SURVEY 8(d) config 5 defines it: 1024 vehicles do not fit one 100x100 map, so the
+    stress instance is ceil(1024/50) = 21 independent worlds - instances ex0..ex20 of the map100by100/agents50/obstacle
+    set in one batch (inter-vehicle planes only inside a world, every world keeps its obstacles), truncated to 1024
+    agents: the last world keeps its first 24 agents with all their planes.  Returns (worlds, infos)."""
+    worlds, infos, left = [], [], int(n_agents)
+    k = 0
+    while left > 0:
+        w, info = map100_world(k % MAP100_SET_SIZE, veh=veh, parm=parm, seed_offset=seed_offset + 1000 * (k // MAP100_SET_SIZE))
+        if w.Na > left:
+            w = w.subset(0, left)
+            info = dict(info, Na=w.Na, n_planes=int(w.plane_off[-1]), truncated_to=left)
+        worlds.append(w)
+        infos.append(info)
+        left -= w.Na
+        k += 1
+    return worlds, infos
+
+
+WORKLOADS = ("map100", "map50", "synth1024")
+
+
+def workload_jobs(name, n_instances=None, seed_offset=0):
+    """(builder, k, seed_offset) jobs of a named bench workload, one per world, for a process pool."""
+    if name == "map100":
+        n = MAP100_SET_SIZE if n_instances is None else max(1, min(int(n_instances), MAP100_SET_SIZE))
+        return [("map100", k, seed_offset) for k in range(n)]
+    if name == "map50":
+        n = MAP50_SET_SIZE if n_instances is None else max(1, min(int(n_instances), MAP50_SET_SIZE))
+        return [("map50", k, seed_offset) for k in range(n)]
+    if name == "synth1024":
+        return [("synth1024", k, seed_offset) for k in range(21)]
+    raise ValueError("unknown workload %r (one of %s)" % (name, ", ".join(WORKLOADS)))
+
+
+def build_job(job):
+    """Build one world of a workload (see workload_jobs); returns (World, info)."""
+    kind, k, seed_offset = job
+    if kind == "map50":
+        return map50_world(k, seed_offset=seed_offset)
+    w, info = map100_world(k, seed_offset=seed_offset)
+    if kind == "synth1024" and k == 20:
+        left = SYNTH1024_AGENTS - 20 * 50
+        w = w.subset(0, left)
+        info = dict(info, Na=w.Na, n_planes=int(w.plane_off[-1]), truncated_to=left)
+    return w, info
+
+
+def job_agents(job):
+    """Number of agents of a workload job's world, known without building it (sharding plans need it up front)."""
+    kind, k, _ = job
+    if kind == "map50":
+        return 25
+    if kind == "synth1024" and k == 20:
+        return SYNTH1024_AGENTS - 20 * 50
+    return 50
+
+
+def build_jobs_parallel(jobs, procs=8, start_method="spawn"):
+    """[(World, info)] for a list of workload jobs, built by a process pool.  `spawn` by default: safe to call from a
+    process that has already initialised the GPU (the workers never touch it)."""
+    procs = max(1, min(int(procs), len(jobs)))
+    if procs == 1:
+        return [build_job(j) for j in jobs]
+    from multiprocessing import get_context
+    with get_context(start_method).Pool(procs) as pool:
+        return pool.map(build_job, jobs)

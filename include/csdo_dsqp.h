@@ -114,7 +114,10 @@ void csdo_dsqp_destroy(csdo_handle h);
 /* Host-buffer entry: upload, solve on the handle's stream, download.  Replaces the SolverDSQP constructor. */
 int csdo_dsqp_solve(csdo_handle h, const csdo_problem* in, csdo_result* out);
 
-/* Several worlds in one launch (agents of all worlds become workgroups of one grid).  results[w] per world. */
+/* Several worlds in one launch (agents of all worlds become workgroups of one grid).  results[w] per world.
+ * One launch reads ONE parameter block: every world of a batch must carry the same `veh` and `parm` as worlds[0]
+ * (CSDO_EINVAL otherwise; solve differently-parameterised worlds in separate calls).  CSDO_ELIMIT if a world's
+ * obstacle list does not fit the 160 KB of LDS beside the exchange vectors. */
 int csdo_dsqp_solve_batch(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds, csdo_result* results);
 
 /* Split-phase form used by bench.py so the timed region starts with inputs resident in HBM:
@@ -124,6 +127,9 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream /* hipStream_t or NULL for the
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
 /* Device time of the last csdo_dsqp_run in seconds (HIP events on the launch stream) and the kernel's own name. */
 double csdo_dsqp_last_kernel_seconds(csdo_handle h);
+/* Host seconds of the last upload / download: out[0] packing the worlds, out[1] staging into page-locked memory,
+ * out[2] H2D copies (+ first-call device allocation), out[3] D2H copies, out[4] scattering into the caller's buffers. */
+int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]);
 /* How the uploaded batch is launched: agents are grouped by kernel class (workgroup size by horizon; LDS residency by
  * working set: 0 = coupling blocks, pivot inverses and bounds all in LDS, 1 = bounds read from the L2-resident workspace,
  * 2 = pivot inverses too, 3 = only the exchange vectors in LDS); every group is a set of persistent workgroups that take

@@ -71,12 +71,7 @@ static void to_problem(const csdo_problem* in, DsqpProblem& P) {
 
 extern "C" {
 
-int csdo_oracle_solve(const csdo_problem* in, csdo_result* out, int n_threads) {
-  if (!in || !out || in->Nt < 2 || in->Na < 1) return CSDO_EINVAL;
-  DsqpProblem P;
-  to_problem(in, P);
-  DsqpResult R;
-  dsqp_solve(P, R, n_threads, nullptr);
+static void copy_out(const csdo_problem* in, const DsqpResult& R, csdo_result* out) {
   for (int a = 0; a < in->Na; ++a) {
     for (int t = 0; t < in->Nt; ++t) {
       const OptRes& r = R.solutions[a][t];
@@ -98,6 +93,29 @@ int csdo_oracle_solve(const csdo_problem* in, csdo_result* out, int n_threads) {
   out->t_max_individual = R.t_max_individual;
   if (out->agent_seconds)
     for (size_t a = 0; a < R.agent_seconds.size(); ++a) out->agent_seconds[a] = R.agent_seconds[a];
+}
+
+int csdo_oracle_solve(const csdo_problem* in, csdo_result* out, int n_threads) {
+  if (!in || !out || in->Nt < 2 || in->Na < 1) return CSDO_EINVAL;
+  DsqpProblem P;
+  to_problem(in, P);
+  DsqpResult R;
+  dsqp_solve(P, R, n_threads, nullptr);
+  copy_out(in, R, out);
+  return CSDO_OK;
+}
+
+// Several worlds, one thread pool over all their agents (the all-core CPU baseline of a batch).
+int csdo_oracle_solve_batch(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int n_threads) {
+  if (!worlds || !results || n_worlds < 1) return CSDO_EINVAL;
+  std::vector<DsqpProblem> P(n_worlds);
+  for (int w = 0; w < n_worlds; ++w) {
+    if (worlds[w].Nt < 2 || worlds[w].Na < 1) return CSDO_EINVAL;
+    to_problem(&worlds[w], P[w]);
+  }
+  std::vector<DsqpResult> R;
+  dsqp_solve_batch(P, R, n_threads);
+  for (int w = 0; w < n_worlds; ++w) copy_out(&worlds[w], R[w], &results[w]);
   return CSDO_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <functional>
 #include <thread>
 
 namespace csdo_oracle {
@@ -800,6 +801,66 @@ void dsqp_solve(const DsqpProblem& prob, DsqpResult& res, int n_threads, std::ve
   for (double s : res.agent_seconds) res.t_max_individual = std::max(res.t_max_individual, s);
   res.t_max_individual += res.t_corridor_max;  // :1245-1248 (shared overhead is ~0 here)
   res.t_total = secs_since(t_begin);
+}
+
+// Several independent worlds (each one SolverDSQP construction) with ONE thread pool over all their agents: the fair
+// all-core CPU figure of SURVEY 8(d)(ii) for a batch - an agent never waits for the slowest agent of its own world.
+// Initial corridors are computed per world by the pool too.  Results per world are exactly those of dsqp_solve.
+void dsqp_solve_batch(const std::vector<DsqpProblem>& probs, std::vector<DsqpResult>& results, int n_threads) {
+  const auto t_begin = clk::now();
+  const int nw = (int)probs.size();
+  results.assign(nw, DsqpResult{});
+  std::vector<std::pair<int, int>> jobs;
+  for (int w = 0; w < nw; ++w) {
+    const int Na = (int)probs[w].x0_bar.size();
+    results[w].solutions.assign(Na, {});
+    results[w].sqp_iters.assign(Na, 0);
+    results[w].admm_iters.assign(Na, 0);
+    results[w].last_status.assign(Na, 1);
+    results[w].agent_seconds.assign(Na, 0.0);
+    for (int a = 0; a < Na; ++a) jobs.push_back({w, a});
+  }
+  const int nt = std::max(1, n_threads);
+  auto run_pool = [&](int n_items, const std::function<void(int)>& fn) {
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int th = 0; th < nt; ++th)
+      pool.emplace_back([&]() {
+        for (;;) {
+          const int i = next.fetch_add(1);
+          if (i >= n_items) break;
+          fn(i);
+        }
+      });
+    for (auto& t : pool) t.join();
+  };
+  run_pool(nw, [&](int w) {
+    results[w].initial_static_legal = calc_corridors(probs[w].x0_bar, probs[w].obstacles, probs[w].dimx, probs[w].dimy,
+                                                     probs[w].veh, results[w].corridors, results[w].t_corridor_max);
+  });
+  run_pool((int)jobs.size(), [&](int i) {
+    const int w = jobs[i].first, a = jobs[i].second;
+    const auto t0 = clk::now();
+    individual_sqp(a, probs[w], results[w], nullptr);
+    results[w].agent_seconds[a] = secs_since(t0);
+  });
+  for (int w = 0; w < nw; ++w) {
+    DsqpResult& res = results[w];
+    bool any_bad = false;
+    int worst = 2;
+    for (size_t a = 0; a < res.last_status.size(); ++a) {
+      const int s = res.last_status[a];
+      if (std::abs(s) > 1) {
+        any_bad = true;
+        if (std::abs(s) > worst) worst = s;
+      }
+    }
+    res.solver_status = any_bad ? worst : 1;
+    res.t_max_individual = 0;
+    for (double s : res.agent_seconds) res.t_max_individual = std::max(res.t_max_individual, s);
+    res.t_max_individual += res.t_corridor_max;
+    res.t_total = secs_since(t_begin);
+  }
 }
 
 }  // namespace csdo_oracle

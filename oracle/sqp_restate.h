@@ -136,4 +136,7 @@ struct DsqpProblem {
 void dsqp_solve(const DsqpProblem& prob, DsqpResult& res, int n_threads = 1,
                 std::vector<SqpTraceEntry>* trace = nullptr);
 
+// The same for several independent worlds with one thread pool over all their agents (bench.py's cpu_baseline).
+void dsqp_solve_batch(const std::vector<DsqpProblem>& probs, std::vector<DsqpResult>& results, int n_threads);
+
 }  // namespace csdo_oracle

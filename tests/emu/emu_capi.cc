@@ -3,7 +3,9 @@
 // the program logic (assembly, Ruiz scaling, block cyclic reduction, ADMM, SQP control, corridors) against the oracle
 // without a GPU.  Never linked into the shipped library.
 #define CSDO_LANE_MODE_SERIAL 1
+#include <atomic>
 #include <cstdio>
+#include <thread>
 #include <vector>
 
 #include "../../csdotrajectoryplanning_amd/csrc/batch_pack.h"
@@ -12,7 +14,9 @@
 using namespace csdo;
 
 // mode: LDS residency of the ADMM blocks (agent_program in dsqp_program.h); all three give identical results
-extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode) {
+// n_threads > 1: agents are solved concurrently (each has its own workspace slice and its own "LDS"), results unchanged
+extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode,
+                                       int n_threads) {
   if (mode < 0 || mode > 3) return CSDO_EINVAL;
   HostBatch hb;
   const int rc = pack_worlds(worlds, n_worlds, hb);
@@ -42,7 +46,7 @@ extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_w
   B.n_agents = Na;
   B.order = nullptr;
   B.prm = hb.prm;
-  for (int a = 0; a < Na; ++a) {
+  auto solve_agent = [&](const int a) {
     const AgentDesc& ad = hb.agents[a];
     const int st = fac_stride(ad.Nt);
     std::vector<double> lds((size_t)100 * st + 3 * hb.max_obs + 32 + 2 * TAIL_N + TAIL_N * 38 + 3 * hb.max_planes, 0.0);
@@ -91,11 +95,30 @@ extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_w
     admm[a] = po.admm_iters;
     stat[a] = po.last_status;
     legal[a] = po.static_legal;
+  };
+  if (n_threads <= 1) {
+    for (int a = 0; a < Na; ++a) solve_agent(a);
+  } else {
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int th = 0; th < n_threads; ++th)
+      pool.emplace_back([&]() {
+        for (;;) {
+          const int a = next.fetch_add(1);
+          if (a >= Na) break;
+          solve_agent(a);
+        }
+      });
+    for (auto& t : pool) t.join();
   }
   unpack_results(hb, worlds, n_worlds, sol.data(), corr.data(), sqp.data(), admm.data(), stat.data(), legal.data(),
                  results);
   for (int w = 0; w < n_worlds; ++w) results[w].t_total = results[w].t_device = results[w].t_max_individual = 0.0;
   return CSDO_OK;
+}
+
+extern "C" int csdo_emu_solve_batch_mode(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode) {
+  return csdo_emu_solve_batch_mt(worlds, n_worlds, results, mode, 1);
 }
 
 extern "C" int csdo_emu_solve_batch(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results) {

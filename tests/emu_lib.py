@@ -23,20 +23,28 @@ def lib():
         _LIB = C.CDLL(os.path.join(_ROOT, "tests", "emu", "libcsdo_emu.so"))
         _LIB.csdo_emu_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result)]
         _LIB.csdo_emu_solve_batch_mode.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
+        _LIB.csdo_emu_solve_batch_mt.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int,
+                                                 C.c_int]
         _LIB.csdo_emu_generate_boxes.argtypes = [abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                                  C.c_double, C.POINTER(abi.Vehicle), abi.c_double_p, abi.c_int32_p]
     return _LIB
 
 
-def solve_batch(worlds, mode=0):
+def solve_batch_rc(worlds, mode=0, n_threads=1):
+    """Return code of the packing + solve (error-path tests) and the solutions."""
     sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
     probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
     res = (abi.Result * len(worlds))(*[s._c for s in sols])
-    rc = lib().csdo_emu_solve_batch_mode(probs, len(worlds), res, mode)
-    assert rc == 0, rc
+    rc = lib().csdo_emu_solve_batch_mt(probs, len(worlds), res, mode, n_threads)
     for s, r in zip(sols, res):
         s._c = r
         s.finish()
+    return rc, sols
+
+
+def solve_batch(worlds, mode=0, n_threads=1):
+    rc, sols = solve_batch_rc(worlds, mode, n_threads)
+    assert rc == 0, rc
     return sols
 
 

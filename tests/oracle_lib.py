@@ -43,6 +43,21 @@ def solve(world: World, n_threads=1) -> Solution:
     return sol.finish()
 
 
+def solve_batch(worlds, n_threads=1):
+    """Several worlds, one thread pool over all their agents (csdo_oracle_solve_batch)."""
+    sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
+    probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
+    res = (abi.Result * len(worlds))(*[s._c for s in sols])
+    f = lib().csdo_oracle_solve_batch
+    f.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
+    rc = f(probs, len(worlds), res, n_threads)
+    assert rc == 0, rc
+    for s, r in zip(sols, res):
+        s._c = r
+        s.finish()
+    return sols
+
+
 def trace(world: World, cap=4096):
     n = 6 * world.Nt - 2
     meta = np.zeros((cap, 4), np.int32)

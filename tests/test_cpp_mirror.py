@@ -1,0 +1,54 @@
+"""The C++ mirror csdo::SolverDSQP (host/solver_dsqp.hpp) compiled against stand-in types shaped like the reference's
+own structs (tests/cpp/mirror_main.cc): builds on CPU; on the GPU box its results equal the ctypes path bit for bit."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "mirror_main")
+
+
+def _build():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+
+
+def test_cpp_mirror_compiles_against_reference_shaped_types():
+    _build()
+    assert os.path.exists(BIN)
+    assert subprocess.run([BIN], capture_output=True).returncode == 2      # usage error, no GPU touched
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path):
+    _build()
+    veh, parm = veh_parm
+    w, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<4i", w.Na, w.Nt, len(w.obstacles), int(w.plane_off[-1])))
+        f.write(struct.pack("<2d", w.dimx, w.dimy))
+        f.write(struct.pack("<7d", parm.r_trust, parm.max_omega, parm.max_v, parm.max_iter,
+                            parm.delta_solution_threshold, parm.max_violation, parm.dt))
+        f.write(struct.pack("<3i", parm.osqp_max_iter, parm.num_interpolation, parm.fixed_corridor))
+        f.write(np.ascontiguousarray(w.x0_bar).tobytes())
+        f.write(np.ascontiguousarray(w.plane_off, dtype=np.int32).tobytes())
+        for p in w.planes:
+            f.write(struct.pack("<i", int(p["t"])))
+            f.write(np.ascontiguousarray(p["c"], dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(w.obstacles).tobytes())
+    r = subprocess.run([BIN, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = open(fout, "rb").read()
+    status, legal = struct.unpack_from("<2i", raw, 0)
+    tmax, = struct.unpack_from("<d", raw, 8)
+    its = np.frombuffer(raw, np.int32, 2 * w.Na, 16).reshape(w.Na, 2)
+    body = np.frombuffer(raw, np.float64, w.Na * w.Nt * 14, 16 + 8 * w.Na).reshape(w.Na, w.Nt, 14)
+    ref = gpu_handle.solve(w)
+    assert status == ref.solver_status and legal == ref.initial_static_legal and tmax > 0
+    assert np.array_equal(its[:, 0], ref.sqp_iters) and np.array_equal(its[:, 1], ref.admm_iters)
+    assert np.array_equal(body[..., :6], ref.solutions) and np.array_equal(body[..., 6:], ref.corridors)

@@ -49,3 +49,44 @@ def test_two_rank_shard_and_gather(tmp_path, emu, veh_parm):
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), f"gather_{r}.npy"))
         assert np.array_equal(got, ref)       # agents are independent: sharding changes nothing, bit for bit
+
+
+def _batch_worker(rank, world_size, port, out_dir):
+    """The bench's strong-scaling step on CPU: contiguous block of the batch's agents -> solve -> FlatGather."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from csdotrajectoryplanning_amd import config
+    from csdotrajectoryplanning_amd.sharding import FlatGather, shard_batch
+    from tests import emu_lib, helpers
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    veh, parm = config.vehicle_from_config(), config.qp_parm_from_config()
+    worlds = [helpers.load_golden(n, veh, parm)[0] for n in ("map50_agents15to17.npz", "map100_agents0to3.npz")]
+    mine = shard_batch(worlds, rank, world_size)                  # 3 + 4 agents -> 4 | 3: the second world is split
+    sols = emu_lib.solve_batch(mine)
+    flat = torch.from_numpy(np.concatenate([s.solutions.reshape(-1) for s in sols]))
+    fg = FlatGather(flat.numel(), dist, torch.device("cpu"))
+    fg.gather(flat)
+    np.save(os.path.join(out_dir, f"flat_{rank}.npy"), torch.cat(fg.parts()).numpy())
+    np.save(os.path.join(out_dir, f"counts_{rank}.npy"), np.array([sum(w.Na for w in mine)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_batch_shard_and_flat_gather(tmp_path, emu, veh_parm):
+    import torch.multiprocessing as mp
+    from csdotrajectoryplanning_amd.sharding import shard_batch_plan
+    from tests import helpers
+    assert shard_batch_plan([3, 4], 0, 2) == [(0, 0, 3), (1, 0, 1)] and shard_batch_plan([3, 4], 1, 2) == [(1, 1, 4)]
+    assert shard_batch_plan([50] * 60, 3, 8) == [(w, lo, hi) for w, lo, hi in
+                                                 [(22, 25, 50)] + [(k, 0, 50) for k in range(23, 30)]]
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_batch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    veh, parm = veh_parm
+    worlds = [helpers.load_golden(n, veh, parm)[0] for n in ("map50_agents15to17.npz", "map100_agents0to3.npz")]
+    ref = np.concatenate([s.solutions.reshape(-1) for s in emu.solve_batch(worlds)])
+    assert [int(np.load(os.path.join(str(tmp_path), f"counts_{r}.npy"))[0]) for r in range(2)] == [4, 3]
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"flat_{r}.npy")), ref)

@@ -18,13 +18,15 @@ _DEG = 180 / 3.14   # the reference's constant, not pi
 
 
 def write_solutions(path, solutions, stats=None):
-    """solutions [Na][Nt][6] = x, y, yaw, steer, v, d_steer; stats: dict with any of the header keys (missing -> 0)."""
+    """solutions [Na][Nt][6] = x, y, yaw, steer, v, d_steer; stats: dict with any of the header keys.  Missing keys take the
+    defaults of the reference's SolutionStatistics (sqp/common.h:25-36): -1 for the floats (cost, makespan, flowtime stay
+    -1 for csdo runs), search_status 2, solver_status 0."""
     stats = stats or {}
     sol = np.asarray(solutions, dtype=np.float64)
     Na, Nt = sol.shape[:2]
     out = ["statistics:"]
     for k in _HEADER:
-        v = stats.get(k, 0)
+        v = stats.get(k, {"search_status": 2, "solver_status": 0}.get(k, -1))
         out.append("  %s: %s" % (k, ("%d" % v) if k.endswith("_status") else ("%.3f" % float(v))))
     out.append("schedule:")
     for a in range(Na):
@@ -103,6 +105,39 @@ def _rect_frames(sol, veh):
     u = np.stack([np.cos(yaw), np.sin(yaw)], -1)
     c = np.stack([x, y], -1) + 0.5 * (veh.LF - veh.LB) * u
     return c, u, 0.5 * (veh.LF + veh.LB), 0.5 * veh.car_width
+
+
+def _pose_frames(p, veh, margin=0.0):
+    p = np.asarray(p, dtype=np.float64)
+    u = np.stack([np.cos(p[..., 2]), np.sin(p[..., 2])], -1)
+    c = p[..., :2] + 0.5 * (veh.LF - veh.LB) * u
+    n = np.stack([-u[..., 1], u[..., 0]], -1)
+    return c, u, n, 0.5 * (veh.LF + veh.LB) + margin, 0.5 * veh.car_width + margin
+
+
+def rect_rect_collision(p, q, veh, margin=0.0):
+    """Vehicle rectangles at rear-axle poses p, q [..., 3] overlap (separating axes; touching counts, as in the
+    reference's collision_rect_and_rect, scripts/collision_detection.py:20-56).  Pinned to the reference's verdicts by
+    tests/golden/ref_collision_verdicts.npz."""
+    ca, ua, na, hl, hw = _pose_frames(p, veh, margin)
+    cb, ub, nb, _, _ = _pose_frames(q, veh, margin)
+    d = cb - ca
+    def sep(ax_u, ax_n, ou, on):
+        eu = hl * np.abs((ou * ax_u).sum(-1)) + hw * np.abs((on * ax_u).sum(-1)) + hl
+        en = hl * np.abs((ou * ax_n).sum(-1)) + hw * np.abs((on * ax_n).sum(-1)) + hw
+        return (np.abs((d * ax_u).sum(-1)) <= eu) & (np.abs((d * ax_n).sum(-1)) <= en)
+    return sep(ua, na, ub, nb) & sep(ub, nb, ua, na)
+
+
+def circle_rect_distance(p, obs, veh, margin=0.0):
+    """Signed distance between the vehicle rectangle at pose p [..., 3] and the disc obs [..., 3] = x, y, r (negative:
+    overlap; the reference's collision_circle_and_rect, scripts/collision_detection.py:59-96, returns True exactly then)."""
+    c, u, n, hl, hw = _pose_frames(p, veh, margin)
+    ob = np.asarray(obs, dtype=np.float64)
+    rel = ob[..., :2] - c
+    lx = np.abs((rel * u).sum(-1)) - hl
+    ly = np.abs((rel * n).sum(-1)) - hw
+    return np.hypot(np.maximum(lx, 0), np.maximum(ly, 0)) + np.minimum(np.maximum(lx, ly), 0) - ob[..., 2]
 
 
 def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0) -> ValidationReport:

@@ -212,9 +212,11 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   unsigned act;             // rows that exist at this t
   int ncols;                // 6, or 4 at t = Nt-1
 };
-struct SolvRegs {           // solver lane of timestep t: BCR node t and the inter-vehicle rows at t
+struct SolvRegs {           // solver lane of timestep t: BCR node t, whole factor in registers during an ADMM block
   double b[6];              // rhs -> BCR work vector -> x_tilde
-  double el[36];            // coupling block to the left neighbour at this node's elimination level (E_r: LDS)
+  double el[36];            // F_l = Sinv E_l: coupling to the left neighbour at this node's elimination level
+  double er[36];            // F_r = E_r Sinv: coupling to the right neighbour            (MODE 3: read from the workspace)
+  double sinv[21];          // inverse of the pivot block, packed lower                   (MODE 3: read from the workspace)
 };
 typedef RowRegs LaneState;  // the row lane is the "home" of a timestep
 
@@ -241,30 +243,35 @@ enum WsSlot {
   C_TOTAL = 210
 };
 
-// lane-major leading dimensions (doubles per lane) of the LDS arrays
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 12, LD_lohi = 22, LD_er = 38, LD_sinvs = 22, LD_tinv = 38;   // 38: the 2h-strided b128 reads of E_r are bank-conflict free
+// lane-major leading dimensions (doubles per lane) of the LDS arrays.  All are 2 * odd: 16-byte aligned lanes, and the
+// ds_read_b128 / ds_write_b128 of 16 consecutive lanes (also of lanes a power of two apart) fall into 16 different
+// 4-bank groups - conflict free.  (12 doubles, the former reduction stride, is 2-way conflicting.)
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_stash = 38,
+              LD_tinv = 38, LD_prow = 26;
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
-  double* vec;      // [stride][6]  rhs / x_tilde / x exchange
+  double* vec;      // [stride][6]  x_tilde / x exchange
   double* pl;       // [stride][6]  BCR partials for the left neighbour (forward sweep only); ALIASES vec: a node's rhs is
                     //              in registers before it publishes its partial, and its x is written in the backward sweep
   double* pr;       // [stride][6]  BCR partials for the right neighbour  (solve only)
-  double* carry;    // [stride][6]  t -> t+1 hand-over; ALIASES pr (dead outside the solve)
-  double* carry2;   // [stride][6]  t -> t-1 hand-over of update_info; ALIASES E_r (only used between ADMM blocks)
+  double* rhs;      // [stride][6]  the row lane's own share of the next rhs: sigma x + A'(rho z - y) of its home rows
+  double* carry;    // [stride][6]  t -> t+1 hand-over (kinematic rows' share of the next rhs; norms in the set-up stage)
+  double* carry2;   // [stride][6]  t -> t-1 hand-over (set-up stage, update_info, feasibility test)
   double* lohi;     // [stride][22] bounds of the home rows during an ADMM block: 0..6 eq rows (lo = hi),
                     //              7..12 lo and 13..18 hi of corridor/trust rows, 19..21 hi of the +-boxes (lo = -hi)
-  double* red;      // [stride][12] reduction scratch; ALIASES lohi (reductions only run between ADMM blocks)
-  double* sinvs;    // [stride][22] pivot-block inverses (packed lower) of the BCR nodes during an ADMM block
-  double* er;       // [stride][38] coupling block E_r of each BCR node (E_l sits in solver-lane registers)
+  double* red;      // [stride][14] reduction scratch; ALIASES vec/pr/rhs (reductions only run between ADMM blocks)
+  double* stash;    // [stride][38] factor-time scratch of an eliminated node (one 6x6 product); ALIASES everything from vec
+                    //              on: the factorisation runs between blocks, bounds and rhs are (re)loaded at a block's start
   double* obs;      // [3][n_obs]
-  double* facE;     // [stride][72] coupling blocks E_l (36) + E_r (36) of every node, lane-major (global; cached in solver registers / LDS during a block)
+  double* facE;     // [stride][72] F_l (36) + F_r (36) of every node, lane-major (global; in solver registers during a block)
   double* facX;     // [100][stride] factor-time exchange and the nodes' diagonal blocks (global, coalesced)
   double* cold;     // [C_TOTAL][stride] per-agent workspace (global)
   double* bcast;    // [32] block-wide results
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
   double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
   double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in MODE 3)
+  double* prow;     // [K][26] MODE 0: the inter-vehicle rows' iteration state of a plane (y, z, u, ca, cb, cyaw x 4 rows)
   int stride;
 };
 
@@ -669,11 +676,13 @@ CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
   else return (S.eqmask & (1u << I)) ? rho_eq : rho;
 }
 
-// MODE: what an ADMM block keeps in LDS beside the 6-vectors, chosen per agent by its working set (dsqp_kernel.hip):
-//   0  coupling blocks E_r, pivot inverses, bounds and per-plane rhs shares                          (94 doubles per timestep)
-//   1  E_r, pivot inverses and the plane shares; the bounds are read from the L2-resident workspace  (72)
-//   2  E_r and the plane shares; pivot inverses and bounds from the workspace                        (50)
-//   3  only the 6-vectors and the reduction scratch: horizons beyond 256                             (30)
+// MODE: where the iteration state of an ADMM block lives, chosen per agent by its working set (dsqp_kernel.hip).  The
+// factor of a BCR node (pivot inverse + both couplings, 93 doubles) sits in its solver lane's REGISTERS in modes 0 and 1.
+//   0  LDS: exchange vectors, bounds of the home rows, the inter-vehicle rows' state and their rhs shares
+//      (52 doubles per timestep + 29 per plane)
+//   1  as 0, but the inter-vehicle rows' state stays in the L2-resident workspace (agents with very many planes)
+//   3  horizons beyond 256 (1024 threads, 128 registers per lane): factor, bounds and rows from the workspace; LDS only
+//      holds the exchange vectors (30 doubles per timestep)
 template <int ROLE, int MODE, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out);

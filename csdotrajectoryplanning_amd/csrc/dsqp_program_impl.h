@@ -13,9 +13,9 @@ namespace csdo {
 // otherwise hoists those out of the loops and spills them: a scratch reload in front of every workspace access)
 #define SX(k, t) (sh.facX + (size_t)(k) * (size_t)sh.stride)[(unsigned)(t)]
 #define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
-// E_r of node t: LDS copy, or the workspace copy for long horizons
-#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : SH(er, k, t))
-#define SINV(k, t) (MODE >= 2 ? WS(W_SINV + (k), t) : SH(sinvs, k, t))
+// F_r and the pivot inverse of node t: the solver lane's registers, or the workspace copy for long horizons
+#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : V.er[k])
+#define SINV(k, t) (MODE == 3 ? WS(W_SINV + (k), t) : V.sinv[k])
 #define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 #define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 
@@ -212,11 +212,11 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
         }
         CSDO_FOR(k, 21, { WS(W_SINV + k, t) = Sinv[k]; });
         if constexpr (MODE != 3) {
-          // Register-lean order: the 6x6 products T = Sinv Rl and V = Sinv Rr' are parked in this lane's (idle) E_r slot
-          // of LDS as they are produced and read back column by column, so that one 6x6 operand, the pivot inverse and a
+          // Register-lean order: the 6x6 products T = Sinv Rl and V = Sinv Rr' are parked in this lane's stash slot of
+          // LDS as they are produced and read back column by column, so that one 6x6 operand, the pivot inverse and a
           // handful of accumulators are all that is live (the all-register version below spills, and a spilled double
           // costs an L2 round trip).  Same products, same summation order, same results.
-#define STASH(k) SH(er, k, t)
+#define STASH(k) SH(stash, k, t)
           {
             double Rl[36];
             CSDO_FOR(k, 36, { Rl[k] = FR(k, t - h); });
@@ -801,23 +801,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         {
           // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed
           double a4[6] = {0, 0, 0, 0, 0, 0};
-          {
-            double tr[TAIL_N / 2], tb[TAIL_N / 2];
-            CSDO_FOR(c, TAIL_N / 2, {
-              tr[c] = SH(tinv, c, t);
-              tb[c] = sh.tvec[c];
+          CSDO_FOR(q, 4, {     // quarters of the row: the solver lanes' registers hold their node's factor
+            double tr[TAIL_N / 4], tb[TAIL_N / 4];
+            CSDO_FOR(c, TAIL_N / 4, {
+              tr[c] = SH(tinv, q * (TAIL_N / 4) + c, t);
+              tb[c] = sh.tvec[q * (TAIL_N / 4) + c];
             });
-            CSDO_FOR(c, TAIL_N / 2, { a4[c % 6] = fma(tr[c], tb[c], a4[c % 6]); });
-          }
-          CSDO_STAGE();
-          {
-            double tr[TAIL_N / 2], tb[TAIL_N / 2];
-            CSDO_FOR(c, TAIL_N / 2, {
-              tr[c] = SH(tinv, TAIL_N / 2 + c, t);
-              tb[c] = sh.tvec[TAIL_N / 2 + c];
-            });
-            CSDO_FOR(c, TAIL_N / 2, { a4[c % 6] = fma(tr[c], tb[c], a4[c % 6]); });
-          }
+            CSDO_FOR(c, TAIL_N / 4, { a4[(q * (TAIL_N / 4) + c) % 6] = fma(tr[c], tb[c], a4[(q * (TAIL_N / 4) + c) % 6]); });
+            CSDO_STAGE();
+          });
           const int kn = t / 6, i = t - 6 * kn;
           sh.vec[(kn * h_tail) * LD_vec + i] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + (a4[4] + a4[5]);
         }
@@ -1200,13 +1192,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq0, S.z[k], -S.y[k]) : 0.0;
         });
       }
-      CSDO_SLANES(t) {  // load the solver-lane cache and the inter-row share of the first rhs
+      CSDO_SLANES(t) {  // load the solver-lane cache: the node's whole factor in registers
         SolvRegs& V = CSDO_SS(t);
-        if constexpr (MODE <= 1) CSDO_FOR(k, 21, { SH(sinvs, k, t) = WS(W_SINV + k, t); });
-        CSDO_FOR(k, 36, {
-          V.el[k] = FE(k, t);
-          if constexpr (MODE != 3) SH(er, k, t) = FE(36 + k, t);
-        });
+        CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
+        if constexpr (MODE != 3) {
+          CSDO_FOR(k, 36, { V.er[k] = FE(36 + k, t); });
+          CSDO_FOR(k, 21, { V.sinv[k] = WS(W_SINV + k, t); });
+        }
       }
       CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, l, nthr, rho); }
       CSDO_SYNC();

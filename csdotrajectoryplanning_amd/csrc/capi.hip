@@ -110,7 +110,8 @@ static int build_groups(csdo_handle h) {
     const AgentDesc& ad = hb.agents[a];
     const int n_obs = hb.worlds[ad.world].n_obs;
     key[a].block = dsqp_agent_class(ad.Nt, n_obs, ad.n_planes, &key[a].mode);
-    if (key[a].mode < h->min_mode) key[a].mode = (h->min_mode < 3 && key[a].block != 512) ? 3 : h->min_mode;
+    // testing knob: push agents to a leaner residency mode (256-thread class: 0, 1; 512: 0, 1, 2; 1024: always 3)
+    if (key[a].block != 1024 && h->min_mode > key[a].mode) key[a].mode = std::min(h->min_mode, key[a].block == 512 ? 2 : 1);
     need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode);
   }
   h->order.resize(Na);
@@ -269,7 +270,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
   // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
   {
-    const double mode_cost[4] = {1.0, 1.0, 1.6, 2.5};
+    const double mode_cost[4] = {1.0, 1.3, 1.3, 2.5};
     std::vector<double> work(h->groups.size(), 0.0);
     double total = 0.0;
     for (size_t g = 0; g < h->groups.size(); ++g) {

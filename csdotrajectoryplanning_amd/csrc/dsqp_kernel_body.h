@@ -8,10 +8,17 @@
 namespace csdo {
 
 // BLOCK = 2 * (lanes per role): threads [0, BLOCK/2) are row lanes, [BLOCK/2, BLOCK) solver lanes (dsqp_program.h)
-// MODE: LDS residency of an ADMM block (0 everything, 1 without pivot inverses and bounds, 2 only the 6-vectors),
-// see agent_program in dsqp_program.h
+// MODE: where an ADMM block keeps its iteration state (0: inter-vehicle rows in LDS, 1: in the workspace, 3: long
+// horizons, factor from the workspace too), see agent_program in dsqp_program.h
 // SPLIT: two specialised lanes per timestep (row waves + solver waves)
-// LDS carve of one agent (see Shm); `lds` is the workgroup's dynamic LDS
+// LDS carve of one agent (see Shm); `lds` is the workgroup's dynamic LDS.  Every array starts 16-byte aligned (even
+// strides) and says so, which lets the compiler use ds_read_b128 / ds_write_b128 on the lane-major arrays.
+template <class T>
+__device__ __forceinline__ T* aligned16(T* p) {
+  __builtin_assume(((unsigned long long)p & 15ull) == 0ull);
+  return (T*)__builtin_assume_aligned(p, 16);
+}
+
 template <int MODE>
 __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, double* lds) {
   const int ad_Nt = uniform_i32(B.agents[agent].Nt);
@@ -19,45 +26,49 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   const long long ad_rows_off = uniform_i64(B.agents[agent].rows_off);
   const int ad_n_planes = uniform_i32(B.agents[agent].n_planes);
   const int n_obs = uniform_i32(B.worlds[uniform_i32(B.agents[agent].world)].n_obs);
-  const int st = (ad_Nt + 1) & ~1;
+  // the stride is built as 2 * (half): every array offset below is then a visible multiple of 16 bytes, and the
+  // compiler may use 16-byte LDS accesses on the lane-major arrays (with a runtime "& ~1" it cannot prove that and
+  // falls back to ds_read2_b64, twice the LDS cycles)
+  const int st = 2 * ((ad_Nt + 1) >> 1);
   Shm sh;
   sh.stride = st;
-  sh.vec = lds;
+  sh.vec = aligned16(lds);
   sh.pl = sh.vec;       // aliases, see Shm
-  sh.pr = sh.vec + 6 * st;
-  sh.carry = sh.pr;
-  double* rest = sh.pr + 6 * st;
-  if constexpr (MODE == 0) {
-    sh.lohi = rest;
-    sh.red = sh.lohi;                     // reductions only run between ADMM blocks
-    sh.sinvs = sh.lohi + 22 * st;
-    sh.er = sh.sinvs + 22 * st;
-    sh.carry2 = sh.er;
-    rest = sh.er + 38 * st;
-  } else if constexpr (MODE == 1) {
-    sh.lohi = nullptr;
-    sh.sinvs = rest;
-    sh.red = sh.sinvs;
-    sh.er = sh.sinvs + 22 * st;
-    sh.carry2 = sh.er;
-    rest = sh.er + 38 * st;
-  } else if constexpr (MODE == 2) {
-    sh.lohi = sh.sinvs = nullptr;
-    sh.er = rest;
-    sh.red = sh.er;
-    sh.carry2 = sh.er + 12 * st;
-    rest = sh.er + 38 * st;
+  sh.pr = aligned16(sh.vec + 6 * st);
+  sh.rhs = aligned16(sh.pr + 6 * st);
+  sh.carry = aligned16(sh.rhs + 6 * st);
+  sh.red = sh.vec;
+  double* rest = sh.carry + 6 * st;
+  if constexpr (MODE != 3) {
+    sh.stash = sh.vec;
+    sh.lohi = aligned16(rest);
+    sh.carry2 = sh.lohi;
+    rest = sh.lohi + 22 * st;
+    if constexpr (MODE < 2) {
+      sh.fx = aligned16(rest);
+      rest = sh.fx + 34 * st;
+    } else {
+      sh.fx = nullptr;
+    }
   } else {
-    sh.lohi = sh.sinvs = sh.er = nullptr;
-    sh.carry2 = rest;
-    sh.red = sh.carry2 + 6 * st;
-    rest = sh.red + 12 * st;
+    sh.stash = sh.lohi = sh.fx = nullptr;
+    sh.carry2 = aligned16(rest);
+    rest = sh.carry2 + 6 * st;
   }
+  const int n_obs_pad = 2 * ((3 * n_obs + 1) >> 1);
   sh.obs = rest;
-  sh.bcast = sh.obs + 3 * n_obs;
-  sh.tvec = sh.bcast + 32;
-  sh.tinv = sh.tvec + 2 * TAIL_N;
-  sh.pc = MODE == 3 ? (B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes) : (sh.tinv + TAIL_N * 38);
+  sh.bcast = aligned16(sh.obs + n_obs_pad);
+  sh.tvec = aligned16(sh.bcast + 32);
+  sh.tinv = aligned16(sh.tvec + 2 * TAIL_N);
+  rest = sh.tinv + TAIL_N * 38;
+  if constexpr (MODE != 0) {
+    sh.pc = B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes;
+    sh.prow = nullptr;
+  } else {
+    const int n_pc_pad = 2 * ((3 * ad_n_planes + 1) >> 1);
+    sh.pc = rest;
+    sh.prow = aligned16(sh.pc + n_pc_pad);
+  }
   double* fac_global = B.fac_ws + ad_fac_off;
   sh.facE = fac_global;
   sh.facX = fac_global + (size_t)FAC_E_DOUBLES * st;

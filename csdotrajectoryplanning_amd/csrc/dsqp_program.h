@@ -199,6 +199,13 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 // ---------------------------------------------------------------------------------------------------------
 // Register state of the two lane roles (each program instantiation only ever touches its own).  Both are caches of the per-agent workspace: loaded at the start of a block of <= check_termination ADMM iterations
 // and written back at its end; every cold phase works from the workspace with short-lived temporaries.
+// How much of a BCR node's factor (F_l 36 + F_r 36 + packed pivot inverse 21 = 93 doubles) its solver lane keeps in
+// registers during an ADMM block: F_l and the first ER_REG entries of F_r.  With everything in registers (198 of the 256
+// the 512-thread kernel has per lane) the allocator spills a third of it to scratch, and a scratch reload inside a BCR
+// level costs more than the LDS read it replaced (measured: 160 ms against 140 ms per step on the map100 set); 60 doubles
+// leave the hot loop spill-free.  The other 33 sit in LDS (Shm::fx): read by one lane, once per sweep.
+constexpr int ER_REG = 24, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
+
 struct RowRegs {            // row lane of timestep t: the 16 home constraint rows and the 6 variables
   double c[NROW][3];        // scaled coefficients on own columns
   double cn[4];             // scaled coefficient of kin rows on column i of t+1
@@ -212,12 +219,12 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   unsigned act;             // rows that exist at this t
   int ncols;                // 6, or 4 at t = Nt-1
 };
-struct SolvRegs {           // solver lane of timestep t: BCR node t, whole factor in registers during an ADMM block
+struct SolvRegs {           // solver lane of timestep t: BCR node t, both couplings in registers during an ADMM block
   double b[6];              // rhs -> BCR work vector -> x_tilde
   double el[36];            // F_l = Sinv E_l: coupling to the left neighbour at this node's elimination level
-  double er[36];            // F_r = E_r Sinv: coupling to the right neighbour            (MODE 3: read from the workspace)
-  double sinv[21];          // inverse of the pivot block, packed lower                   (MODE 3: read from the workspace)
-};
+  double er[ER_REG];        // F_r = E_r Sinv: coupling to the right neighbour, first ER_REG entries (the rest: LDS, Shm::fx;
+};                          //                                                              MODE 3: all from the workspace)                          // (the pivot inverse, only needed in the forward sweep, sits in LDS: with it the lane would
+                            //  hold 198 of its 256 registers and the compiler spills a third of the factor to scratch)
 typedef RowRegs LaneState;  // the row lane is the "home" of a timestep
 
 // Per-agent workspace in HBM (L2-resident), SoA [slot][stride]: the master copy of every per-lane quantity.
@@ -246,8 +253,8 @@ enum WsSlot {
 // lane-major leading dimensions (doubles per lane) of the LDS arrays.  All are 2 * odd: 16-byte aligned lanes, and the
 // ds_read_b128 / ds_write_b128 of 16 consecutive lanes (also of lanes a power of two apart) fall into 16 different
 // 4-bank groups - conflict free.  (12 doubles, the former reduction stride, is 2-way conflicting.)
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_stash = 38,
-              LD_tinv = 38, LD_prow = 26;
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 34,
+              LD_stash = 38, LD_tinv = 38, LD_prow = 10;
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {
@@ -257,10 +264,13 @@ struct Shm {
   double* pr;       // [stride][6]  BCR partials for the right neighbour  (solve only)
   double* rhs;      // [stride][6]  the row lane's own share of the next rhs: sigma x + A'(rho z - y) of its home rows
   double* carry;    // [stride][6]  t -> t+1 hand-over (kinematic rows' share of the next rhs; norms in the set-up stage)
-  double* carry2;   // [stride][6]  t -> t-1 hand-over (set-up stage, update_info, feasibility test)
+  double* carry2;   // [stride][6]  t -> t-1 hand-over (set-up stage, update_info, feasibility test); ALIASES lohi in modes 0, 1
+                    //              (only used between ADMM blocks; the bounds are reloaded at a block's start)
   double* lohi;     // [stride][22] bounds of the home rows during an ADMM block: 0..6 eq rows (lo = hi),
                     //              7..12 lo and 13..18 hi of corridor/trust rows, 19..21 hi of the +-boxes (lo = -hi)
   double* red;      // [stride][14] reduction scratch; ALIASES vec/pr/rhs (reductions only run between ADMM blocks)
+  double* fx;       // [stride][34] the part of a BCR node's factor that does not fit its solver lane's registers during an
+                    //              ADMM block: F_r[24..36) and the pivot-block inverse (packed lower, 21)
   double* stash;    // [stride][38] factor-time scratch of an eliminated node (one 6x6 product); ALIASES everything from vec
                     //              on: the factorisation runs between blocks, bounds and rhs are (re)loaded at a block's start
   double* obs;      // [3][n_obs]
@@ -271,7 +281,7 @@ struct Shm {
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
   double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
   double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in MODE 3)
-  double* prow;     // [K][26] MODE 0: the inter-vehicle rows' iteration state of a plane (y, z, u, ca, cb, cyaw x 4 rows)
+  double* prow;     // [K][10] MODE 0: duals and slacks (y[4], z[4]) of a plane's four inter-vehicle rows during an ADMM block
   int stride;
 };
 
@@ -329,7 +339,9 @@ CSDO_FN void red_fold(const Shm& sh, int Nt, double (&out)[K]) {
     });
   }
   __syncthreads();
-  CSDO_FOR(k, K, { out[k] = sh.bcast[k]; });
+  // every lane reads the same LDS word: hand the result over in scalar registers (a block-uniform double that stays in
+  // vector registers - the residual norms, rho - costs two of them for as long as it lives, across whole ADMM blocks)
+  CSDO_FOR(k, K, { out[k] = uniform_f64(sh.bcast[k]); });
   __syncthreads();
 #else
   CSDO_FOR(k, K, {
@@ -676,11 +688,13 @@ CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
   else return (S.eqmask & (1u << I)) ? rho_eq : rho;
 }
 
-// MODE: where the iteration state of an ADMM block lives, chosen per agent by its working set (dsqp_kernel.hip).  The
-// factor of a BCR node (pivot inverse + both couplings, 93 doubles) sits in its solver lane's REGISTERS in modes 0 and 1.
-//   0  LDS: exchange vectors, bounds of the home rows, the inter-vehicle rows' state and their rhs shares
-//      (52 doubles per timestep + 29 per plane)
-//   1  as 0, but the inter-vehicle rows' state stays in the L2-resident workspace (agents with very many planes)
+// MODE: where the iteration state of an ADMM block lives, chosen per agent by its working set (dsqp_kernel.hip).  Both
+// coupling F_l and two thirds of F_r of a BCR node (60 doubles) sit in its solver lane's REGISTERS in modes 0 and 1.
+//   0  LDS: exchange vectors, bounds of the home rows, the rest of the factor (33 doubles), duals / slacks of the
+//      inter-vehicle rows and their rhs shares (80 doubles per timestep + 13 per plane)
+//   1  as 0, but the inter-vehicle rows' state and rhs shares stay in the L2-resident workspace (agents with very many
+//      planes; 80 doubles per timestep)
+//   2  as 1, and the third of the factor that is not in registers comes from the workspace (horizons 235..256; 46)
 //   3  horizons beyond 256 (1024 threads, 128 registers per lane): factor, bounds and rows from the workspace; LDS only
 //      holds the exchange vectors (30 doubles per timestep)
 template <int ROLE, int MODE, class RowStore, class SolvStore>

@@ -13,9 +13,10 @@ namespace csdo {
 // otherwise hoists those out of the loops and spills them: a scratch reload in front of every workspace access)
 #define SX(k, t) (sh.facX + (size_t)(k) * (size_t)sh.stride)[(unsigned)(t)]
 #define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
-// F_r and the pivot inverse of node t: the solver lane's registers, or the workspace copy for long horizons
-#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : V.er[k])
-#define SINV(k, t) (MODE == 3 ? WS(W_SINV + (k), t) : V.sinv[k])
+// F_r of node t: the solver lane's registers for the first ER_REG entries, LDS for the rest and for the pivot inverse;
+// everything from the workspace for long horizons
+#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 2 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t))))
+#define SINV(k, t) (MODE >= 2 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 #define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 #define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 
@@ -631,16 +632,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       double c_temp = r[0] / (double)n_vars;
       c_temp = osqp_max(c_temp, limit_scaling(0.0));  // ||q||_inf = 0 -> 1 (q = 0, :196-197)
       c_temp = limit_scaling(c_temp);
-      c_temp = 1.0 / c_temp;
+      c_temp = uniform_f64(1.0 / c_temp);
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
         S.Pvv *= c_temp;
         S.Pww *= c_temp;
         S.Pvn *= c_temp;
       }
-      cscale *= c_temp;
+      cscale = uniform_f64(cscale * c_temp);
     }
-    const double cinv = 1.0 / cscale;
+    const double cinv = uniform_f64(1.0 / cscale);
 
   CSDO_PHASE(4);
     // ============================================================== scaled bounds, row classes, warm start
@@ -739,30 +740,24 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if ((t & m2) == h) {
 #endif
             CSDO_LVL_BEGIN();
-            // three independent 6x6 products of the same b: w = Sinv b, pl = F_l' b, pr = F_r b.
+            // three independent 6x6 products of the same b: pl = F_l' b, pr = F_r b (couplings in registers: published
+            // first, the neighbours wait for them), then w = Sinv b with the pivot inverse fetched from LDS last, so that
+            // its 21 doubles are not live beside the other products' accumulators.
             // fp64 FMAs need >= ~11 independent accumulation chains to issue back to back (measured: 6 chains run
             // at ~7 cycles per FMA, scripts/microbench.hip), so every product is split into two half-sums.
             const bool has_r = (t + h) < Nt;
             double bb[6];
             CSDO_FOR(k, 6, { bb[k] = V.b[k]; });
-            double sv[21];
-            CSDO_FOR(k, 21, { sv[k] = SINV(k, t); });
-            double pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
-            CSDO_FOR(r, 3, {
-              CSDO_FOR(c, 6, {
-                pa[c] = fma(V.el[r * 6 + c], bb[r], pa[c]);
-                pb[c] = fma(V.el[(r + 3) * 6 + c], bb[r + 3], pb[c]);
+            {
+              double pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
+              CSDO_FOR(r, 3, {
+                CSDO_FOR(c, 6, {
+                  pa[c] = fma(V.el[r * 6 + c], bb[r], pa[c]);
+                  pb[c] = fma(V.el[(r + 3) * 6 + c], bb[r + 3], pb[c]);
+                });
               });
-            });
-            CSDO_FOR(c, 6, { SH(pl, c, t) = pa[c] + pb[c]; });
-            double wa[6] = {0, 0, 0, 0, 0, 0}, wb[6] = {0, 0, 0, 0, 0, 0};
-            CSDO_FOR(c, 3, {
-              CSDO_FOR(r, 6, {
-                wa[r] = fma(sv[sym(r, c)], bb[c], wa[r]);
-                wb[r] = fma(sv[sym(r, c + 3)], bb[c + 3], wb[r]);
-              });
-            });
-            CSDO_FOR(k, 6, { V.b[k] = wa[k] + wb[k]; });
+              CSDO_FOR(c, 6, { SH(pl, c, t) = pa[c] + pb[c]; });
+            }
             if (has_r) {
               double er_[36];
               CSDO_FOR(k, 36, { er_[k] = ER(k, t); });
@@ -775,6 +770,24 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               });
               CSDO_FOR(arow, 6, { SH(pr, arow, t) = qa[arow] + qb[arow]; });
             }
+            CSDO_STAGE();
+            // w = Sinv b, three rows at a time: 15 of the 21 packed entries and 9 accumulation chains are live at once
+            // (with all 21 + 12 chains beside the 72 doubles of couplings the allocator spills a third of the factor)
+            double w6[6];
+            CSDO_FOR(half, 2, {
+              double sv[6][6];
+              CSDO_FOR(r3, 3, {
+                CSDO_FOR(c, 6, { sv[r3][c] = SINV(sym(3 * half + r3, c), t); });
+              });
+              CSDO_FOR(r3, 3, {
+                const double s01 = fma(sv[r3][1], bb[1], sv[r3][0] * bb[0]);
+                const double s23 = fma(sv[r3][3], bb[3], sv[r3][2] * bb[2]);
+                const double s45 = fma(sv[r3][5], bb[5], sv[r3][4] * bb[4]);
+                w6[3 * half + r3] = (s01 + s23) + s45;
+              });
+              CSDO_STAGE();
+            });
+            CSDO_FOR(k, 6, { V.b[k] = w6[k]; });
             CSDO_LVL_END(lvl_fwd);
           }
         }
@@ -1117,7 +1130,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     auto plane_pass = [&](auto update_c, auto keep_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
       constexpr bool KEEP = decltype(keep_c)::value;
-      const double rinv = 1.0 / rho_now;
+      const double rinv = uniform_f64(1.0 / rho_now);
       for (int p = lane; p < K_planes; p += nthr) {
         double zz[4], yy[4], ca[4], cb[4], cy[4], uu[4], xt[3] = {0, 0, 0};
         CSDO_FOR(q, 4, {
@@ -1170,7 +1183,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             if constexpr (row_col(i, s) >= 0) S.c[i][s] = WS(W_C + 3 * i + s, t);
           });
           // bounds are read once per iteration: LDS, not registers (layout: Shm::lohi)
-          if constexpr (MODE == 0) {
+          if constexpr (MODE != 3) {
             if constexpr (i < 7) SH(lohi, i, t) = WS(W_LO + i, t);
             if constexpr (i >= 7 && i < 13) {
               SH(lohi, i, t) = WS(W_LO + i, t);
@@ -1187,22 +1200,26 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         S.eqmask = (unsigned)WS(W_EQ, t);
         S.loosemask = (unsigned)WS(W_LOOSE, t);
         S.ncols = (t < Nm) ? 6 : 4;
-        const double rho_eq0 = RHO_EQ_OVER_RHO_INEQ * rho;
+        const double rho_eq0 = uniform_f64(RHO_EQ_OVER_RHO_INEQ * rho);
         CSDO_FOR(k, 4, {
           SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq0, S.z[k], -S.y[k]) : 0.0;
         });
       }
-      CSDO_SLANES(t) {  // load the solver-lane cache: the node's whole factor in registers
+      CSDO_SLANES(t) {  // load the solver-lane cache: 60 doubles of the node's factor in registers, 33 in LDS
         SolvRegs& V = CSDO_SS(t);
         CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
         if constexpr (MODE != 3) {
-          CSDO_FOR(k, 36, { V.er[k] = FE(36 + k, t); });
-          CSDO_FOR(k, 21, { V.sinv[k] = WS(W_SINV + k, t); });
+          CSDO_FOR(k, ER_REG, { V.er[k] = FE(36 + k, t); });
+          if constexpr (MODE < 2) {
+            CSDO_FOR(k, FX_ER, { SH(fx, k, t) = FE(36 + ER_REG + k, t); });
+            CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
+          }
         }
       }
       CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, l, nthr, rho); }
       CSDO_SYNC();
-      const double rho_eq = RHO_EQ_OVER_RHO_INEQ * rho, rinv_in = 1.0 / rho, rinv_eq = 1.0 / rho_eq;
+      const double rho_eq = uniform_f64(RHO_EQ_OVER_RHO_INEQ * rho), rinv_in = uniform_f64(1.0 / rho),
+                   rinv_eq = uniform_f64(1.0 / rho_eq);
       auto iteration = [&](auto keep_c) __attribute__((always_inline)) {
         constexpr bool keep_dy = decltype(keep_c)::value;   // only the last iteration of a block records delta_y
         CSDO_PHASE(6);
@@ -1238,10 +1255,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #endif
         CSDO_LANES_HOT(t) {
           LaneState& S = CSDO_LS(t);
-          // modes >= 1: the 22 bounds of the home rows come from the workspace; one batch of loads in front of everything
+          // mode 3: the 22 bounds of the home rows come from the workspace; one batch of loads in front of everything
           // else of the update (a load per row inside the loop below costs an L2 round trip each)
           double bnd[22];
-          if constexpr (MODE != 0) {
+          if constexpr (MODE == 3) {
             CSDO_FOR(k, 13, { bnd[k] = WS(W_LO + k, t); });
             CSDO_FOR(k, 6, { bnd[13 + k] = WS(W_HI + 7 + k, t); });
             CSDO_FOR(k, 3, { bnd[19 + k] = WS(W_HI + 13 + k, t); });
@@ -1260,14 +1277,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               const double rinv = rho_row<i>(S, rinv_in, rinv_eq);   // = 1.0 / rh (rho_inv_vec of OSQP)
               const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
               double lo_i, hi_i;
-              // bounds in the packed order of Shm::lohi: from LDS, or (modes >= 1) from the batch fetched above
-              if constexpr (i < 7) lo_i = hi_i = (MODE != 0) ? bnd[i] : SH(lohi, i, t);
+              // bounds in the packed order of Shm::lohi: from LDS, or (mode 3) from the batch fetched above
+              if constexpr (i < 7) lo_i = hi_i = (MODE == 3) ? bnd[i] : SH(lohi, i, t);
               if constexpr (i >= 7 && i < 13) {
-                lo_i = (MODE != 0) ? bnd[i] : SH(lohi, i, t);
-                hi_i = (MODE != 0) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                lo_i = (MODE == 3) ? bnd[i] : SH(lohi, i, t);
+                hi_i = (MODE == 3) ? bnd[i + 6] : SH(lohi, i + 6, t);
               }
               if constexpr (i >= 13) {
-                hi_i = (MODE != 0) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                hi_i = (MODE == 3) ? bnd[i + 6] : SH(lohi, i + 6, t);
                 lo_i = -hi_i;
               }
               const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], lo_i), hi_i);
@@ -1331,7 +1348,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         double est = rho * sqrt(pri / (dua + 1e-10));
         est = osqp_min(osqp_max(est, RHO_MIN), RHO_MAX);
         if (est > rho * P.adaptive_rho_tolerance || est < rho / P.adaptive_rho_tolerance) {
-          rho = osqp_min(osqp_max(est, RHO_MIN), RHO_MAX);
+          rho = uniform_f64(osqp_min(osqp_max(est, RHO_MIN), RHO_MAX));
           factor(rho);
         }
       }

@@ -1,4 +1,5 @@
-"""Diagnostic: where the CU time of a batch goes, summed over all agents (needs `make -C csdotrajectoryplanning_amd/csrc prof`)."""
+"""Diagnostic: where the CU time of a batch goes, summed over all agents (needs `make -C csdotrajectoryplanning_amd/csrc prof`).
+usage: python scripts/profile_phases_sum.py [instance ids, comma separated] [map100|map50]"""
 import ctypes as C
 import os
 import sys
@@ -10,7 +11,8 @@ from csdotrajectoryplanning_amd.solver import DsqpHandle  # noqa: E402
 NAMES = ["other", "corridor", "assemble", "ruiz", "warmstart", "factor", "rhs", "solve_fwd", "solve_bwd", "update",
          "info/check", "bookkeeping", "hot load/save", "fwd barrier", "bwd barrier", "-"]
 ids = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 1, 2, 4]
-worlds = [workloads.map100_world(k)[0] for k in ids]
+wl = sys.argv[2] if len(sys.argv) > 2 else "map100"
+worlds = [(workloads.map100_world(k) if wl == "map100" else workloads.map50_world(k))[0] for k in ids]
 h = DsqpHandle(0)
 h.upload(worlds); h.run(); ks = h.run(); sols = h.download()
 Na = sum(w.Na for w in worlds)
@@ -19,10 +21,23 @@ ph = np.zeros((Na, 48), np.int64); tk = np.zeros(Na, np.int64)
 L.csdo_debug_phase_ticks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 assert L.csdo_debug_phase_ticks(h._h, ph.ctypes.data, tk.ctypes.data) == 0
 it = np.concatenate([s.admm_iters for s in sols]); sq = np.concatenate([s.sqp_iters for s in sols])
+print("workload %s instances %s: kernel %.1f ms, Nt %s" % (wl, ids, ks * 1e3, sorted(set(w.Nt for w in worlds))))
 for label, sel in (("all agents", it >= 0), ("short agents (< 1000 iterations)", it < 1000), ("long agents", it >= 1000)):
+    if sel.sum() == 0:
+        continue
     p = ph[sel][:, :16].sum(0).astype(float); tot = p.sum()
     print("%s: %d agents, %d ADMM iterations, %d SQP iterations, %.1f ms of CU time (%.1f us per iteration, %.2f ms per SQP iteration)" % (
         label, sel.sum(), it[sel].sum(), sq[sel].sum(), tk[sel].sum() * 1e-5, tk[sel].sum() * 1e-2 / max(it[sel].sum(), 1), tk[sel].sum() * 1e-5 / max(sq[sel].sum(), 1)))
     print("   " + "  ".join("%s %.1f%%" % (n, 100.0 * p[i] / tot) for i, n in enumerate(NAMES[:15])))
-
     print("   cycles per SQP iteration: " + "  ".join("%s %.0fk" % (NAMES[i], p[i] / max(sq[sel].sum(), 1) / 1e3) for i in (1, 2, 3, 4, 5, 10, 11, 12)))
+    n_it = max(it[sel].sum(), 1)
+    print("   cycles per ADMM iteration: " + "  ".join("%s %.0f" % (NAMES[i], p[i] / n_it) for i in (6, 7, 13, 8, 14, 9)) +
+          "  | iteration total %.0f" % (sum(p[i] for i in (6, 7, 13, 8, 14, 9)) / n_it))
+    # per-level cycles inside the elimination block of solver lane t = 2^lv (forward / backward), per ADMM iteration of the
+    # agents that have that level
+    fw = ph[sel][:, 16:24].astype(float); bw = ph[sel][:, 32:40].astype(float)
+    itv = it[sel][:, None].astype(float)
+    has = fw > 0
+    print("   cycles inside a level's elimination block (lane 2^lv), fwd: " +
+          " ".join("%.0f" % ((fw[:, lv][has[:, lv]] / itv[has[:, lv], 0]).mean() if has[:, lv].any() else 0) for lv in range(6)) +
+          "  bwd: " + " ".join("%.0f" % ((bw[:, lv][has[:, lv]] / itv[has[:, lv], 0]).mean() if has[:, lv].any() else 0) for lv in range(6)))

@@ -13,7 +13,7 @@
 
 using namespace csdo;
 
-// mode: LDS residency of the ADMM blocks (agent_program in dsqp_program.h); all three give identical results
+// mode: residency of the ADMM blocks' state (agent_program in dsqp_program.h): 0 .. 3; all give identical results
 // n_threads > 1: agents are solved concurrently (each has its own workspace slice and its own "LDS"), results unchanged
 extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode,
                                        int n_threads) {
@@ -49,35 +49,39 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
   auto solve_agent = [&](const int a) {
     const AgentDesc& ad = hb.agents[a];
     const int st = fac_stride(ad.Nt);
-    std::vector<double> lds((size_t)100 * st + 3 * hb.max_obs + 32 + 2 * TAIL_N + TAIL_N * 38 + 3 * hb.max_planes, 0.0);
+    // the same carve as dsqp_kernel_body.h (modes 0, 1: bounds in "LDS"; 0: the inter-vehicle rows' state too; 3: lean)
+    std::vector<double> lds((size_t)80 * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N + TAIL_N * 38 +
+                            (size_t)(3 + LD_prow) * hb.max_planes + 4, 0.0);
     Shm sh{};
     sh.stride = st;
     sh.vec = lds.data();
-    sh.pl = sh.vec;       // aliases, see Shm and dsqp_kernel_body.h
+    sh.pl = sh.vec;
     sh.pr = sh.vec + 6 * st;
-    sh.carry = sh.pr;
-    sh.lohi = sh.pr + 6 * st;
-    sh.red = sh.lohi;
-    sh.sinvs = sh.lohi + 22 * st;
-    sh.er = sh.sinvs + 22 * st;
-    sh.carry2 = sh.er;
-    sh.obs = sh.er + 38 * st;
-    sh.bcast = sh.obs + 3 * hb.max_obs;
+    sh.rhs = sh.pr + 6 * st;
+    sh.carry = sh.rhs + 6 * st;
+    sh.red = sh.vec;
+    double* rest = sh.carry + 6 * st;
+    if (mode != 3) {
+      sh.stash = sh.vec;
+      sh.lohi = rest;
+      sh.carry2 = sh.lohi;
+      rest = sh.lohi + 22 * st;
+      if (mode < 2) {
+        sh.fx = rest;
+        rest = sh.fx + 34 * st;
+      }
+    } else {
+      sh.carry2 = rest;
+      rest = sh.carry2 + 6 * st;
+    }
+    sh.obs = rest;
+    sh.bcast = sh.obs + ((3 * hb.max_obs + 1) & ~1);
     sh.tvec = sh.bcast + 32;
     sh.tinv = sh.tvec + 2 * TAIL_N;
     sh.pc = sh.tinv + TAIL_N * 38;
+    sh.prow = mode == 0 ? sh.pc + ((3 * hb.max_planes + 1) & ~1) : nullptr;
     std::vector<double> pc_ws;
-    if (mode == 1) {            // as dsqp_kernel_body.h: no bounds in LDS, reductions over the pivot-inverse region
-      sh.lohi = nullptr;
-      sh.red = sh.sinvs;
-    } else if (mode == 2) {     // no bounds / pivot inverses in LDS, reductions and hand-over in the E_r region
-      sh.lohi = sh.sinvs = nullptr;
-      sh.red = sh.er;
-      sh.carry2 = sh.er + 12 * st;
-    } else if (mode == 3) {     // only the 6-vectors, the hand-over and the reduction scratch
-      sh.carry2 = sh.lohi;
-      sh.red = sh.carry2 + 6 * st;
-      sh.lohi = sh.sinvs = sh.er = nullptr;
+    if (mode != 0) {
       pc_ws.assign((size_t)3 * hb.max_planes + 1, 0.0);
       sh.pc = pc_ws.data();
     }

@@ -85,18 +85,18 @@ def test_gpu_is_deterministic_and_handle_is_reusable(gpu_handle, veh_parm):
 
 
 def test_gpu_lds_residency_modes_are_bit_identical(gpu_handle, veh_parm):
-    """Agents whose working set exceeds LDS read the bounds (mode 1), also the pivot inverses (mode 2) or also the coupling
-    blocks (mode 3) from the workspace: same doubles, same arithmetic, so bit-identical results."""
+    """Agents whose working set exceeds LDS keep the inter-vehicle rows' state in the workspace (mode 1): same doubles,
+    same arithmetic, so bit-identical results.  (Mode 3, horizons beyond 256, is covered by the long-horizon test.)"""
     veh, parm = veh_parm
     w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     w2, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)      # Nt = 169: 512-thread class
     ref = gpu_handle.solve_batch([w1, w2])
     try:
-        for mode in (1, 2, 3):
+        for mode in (1, 2):
             gpu_handle.set_min_residency_mode(mode)
             got = gpu_handle.solve_batch([w1, w2])
             groups = gpu_handle.launch_groups()
-            assert all(g["residency_mode"] >= mode for g in groups) and sum(g["n_agents"] for g in groups) == w1.Na + w2.Na
+            assert all(g["residency_mode"] >= min(mode, 2 if g["threads"] == 512 else 1) for g in groups) and sum(g["n_agents"] for g in groups) == w1.Na + w2.Na
             for r, g in zip(ref, got):
                 assert np.array_equal(r.solutions, g.solutions) and np.array_equal(r.corridors, g.corridors)
                 assert np.array_equal(r.admm_iters, g.admm_iters) and np.array_equal(r.last_status, g.last_status)

@@ -55,8 +55,8 @@ def test_batch_of_worlds_equals_separate_solves(emu, veh_parm):
 
 
 def test_lds_residency_modes_are_bit_identical(emu, veh_parm):
-    """The four LDS residency modes of the ADMM block (agent_program MODE 0..3: which operands come from LDS and which
-    from the workspace) only change where the same doubles are read from."""
+    """The residency modes of the ADMM block (agent_program MODE 0, 1, 3: which operands come from LDS / registers and
+    which from the workspace) only change where the same doubles are read from."""
     veh, parm = veh_parm
     world, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     ref = emu.solve(world, 0)

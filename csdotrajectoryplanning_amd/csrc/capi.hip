@@ -106,13 +106,18 @@ static int build_groups(csdo_handle h) {
   struct Key { int block; int mode; };
   std::vector<Key> key(Na);
   std::vector<size_t> need(Na);
+  HostBatch& hbm = h->hb;
   for (int a = 0; a < Na; ++a) {
-    const AgentDesc& ad = hb.agents[a];
+    AgentDesc& ad = hbm.agents[a];
     const int n_obs = hb.worlds[ad.world].n_obs;
-    key[a].block = dsqp_agent_class(ad.Nt, n_obs, ad.n_planes, &key[a].mode);
-    // testing knob: push agents to a leaner residency mode (256-thread class: 0, 1; 512: 0, 1, 2; 1024: always 3)
-    if (key[a].block != 1024 && h->min_mode > key[a].mode) key[a].mode = std::min(h->min_mode, key[a].block == 512 ? 2 : 1);
-    need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode);
+    int rows = 0;
+    key[a].block = dsqp_agent_class(ad.Nt, n_obs, ad.n_planes, &key[a].mode, &rows);
+    // testing knob (results never depend on it): 1 keeps the inter-vehicle rows' state in the workspace, 2 also reads the
+    // LDS part of the factor from the workspace (512-thread class; the 1024-thread class is always mode 3)
+    if (h->min_mode >= 1) rows = 0;
+    if (h->min_mode >= 2 && key[a].block == 512) key[a].mode = 1;
+    ad.rows_lds = rows;
+    need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode, rows != 0);
   }
   h->order.resize(Na);
   for (int a = 0; a < Na; ++a) h->order[a] = a;
@@ -270,7 +275,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
   // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
   {
-    const double mode_cost[4] = {1.0, 1.3, 1.3, 2.5};
+    const double mode_cost[4] = {1.0, 1.2, 1.2, 2.5};
     std::vector<double> work(h->groups.size(), 0.0);
     double total = 0.0;
     for (size_t g = 0; g < h->groups.size(); ++g) {

@@ -16,7 +16,7 @@ struct AgentDesc {
   int32_t Nt;          // horizon of this agent's world
   int32_t world;       // index into WorldDesc
   int32_t n_planes;    // K_a
-  int32_t _pad;
+  int32_t rows_lds;    // 1: the inter-vehicle rows' duals / slacks / rhs shares fit LDS beside the rest (set by the launcher)
   int64_t x0_off;      // element offset of x0[Nt][6] (in doubles)
   int64_t plane_off;   // first plane of this agent
   int64_t tstart_off;  // offset of tstart[Nt+1]

@@ -34,29 +34,31 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
   boxes[4 * i + 3] = b.y_max;
 }
 
-size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode) {
+size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) {
   const int st = (nt + 1) & ~1;
-  // exchange vectors vec, pr, rhs, carry (6 each) + bounds of the home rows 22 + the third of the factor that is not in
-  // the solver lane's registers 34 (modes 0, 1: the t -> t-1 hand-over aliases the bounds); mode 3: vec, pr, rhs, carry,
-  // carry2
-  const size_t per_lane = mode == 3 ? 30 : (mode == 2 ? 46 : 80);
+  // exchange vectors vec, pr, rhs, carry (6 each) + bounds of the home rows 22 (the t -> t-1 hand-over aliases them) +
+  // the third of the factor that is not in the solver lane's registers 34 (mode 0); mode 3: vec, pr, rhs, carry, carry2
+  const size_t per_lane = mode == 3 ? 30 : (mode == 1 ? 46 : 80);
   const size_t n_obs_pad = (3 * (size_t)n_obs + 1) & ~(size_t)1, n_pc_pad = (3 * (size_t)n_planes + 1) & ~(size_t)1;
-  size_t planes = 0;
-  if (mode == 0) planes = n_pc_pad + (size_t)LD_prow * n_planes;   // per-plane rhs shares + the rows' duals and slacks
+  const size_t planes = (mode == 0 && rows_lds) ? n_pc_pad + (size_t)LD_prow * n_planes : 0;   // rhs shares + duals / slacks
   return (per_lane * st + n_obs_pad + 32 + 2 * TAIL_N + TAIL_N * 38 + planes) * sizeof(double);
 }
 
 constexpr size_t LDS_CAP = 160 * 1024 - 64;   // 160 KB per workgroup minus the kernel's static LDS (queue slot)
 size_t dsqp_lds_capacity() { return LDS_CAP; }
 
-int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode) {
+int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) {
   // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024
   // threads with 128 registers per lane: correct but spills; horizons that long are outside the benchmark sets)
   const int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : 1024);
+  *rows_lds = 0;
   if (block == 1024) {
     *mode = 3;
+  } else if (dsqp_lds_bytes(nt, n_obs, n_planes, 0, true) <= LDS_CAP) {
+    *mode = 0;
+    *rows_lds = 1;
   } else {
-    *mode = dsqp_lds_bytes(nt, n_obs, n_planes, 0) <= LDS_CAP ? 0 : (dsqp_lds_bytes(nt, n_obs, n_planes, 1) <= LDS_CAP ? 1 : 2);
+    *mode = dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) <= LDS_CAP ? 0 : 1;
   }
   return block;
 }
@@ -66,10 +68,8 @@ hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroup
   if (g.lds_bytes > LDS_CAP) return hipErrorInvalidValue;
   switch (g.block * 10 + g.mode) {
     case 2560: return launch_variant<256, 0, true>(B, g, workgroups, stream);
-    case 2561: return launch_variant<256, 1, true>(B, g, workgroups, stream);
     case 5120: return launch_variant<512, 0, true>(B, g, workgroups, stream);
     case 5121: return launch_variant<512, 1, true>(B, g, workgroups, stream);
-    case 5122: return launch_variant<512, 2, true>(B, g, workgroups, stream);
     case 10243: return launch_variant<1024, 3, true>(B, g, workgroups, stream);
   }
   return hipErrorInvalidValue;

@@ -8,8 +8,8 @@
 namespace csdo {
 
 // BLOCK = 2 * (lanes per role): threads [0, BLOCK/2) are row lanes, [BLOCK/2, BLOCK) solver lanes (dsqp_program.h)
-// MODE: where an ADMM block keeps its iteration state (0: inter-vehicle rows in LDS, 1: in the workspace, 3: long
-// horizons, factor from the workspace too), see agent_program in dsqp_program.h
+// MODE: where an ADMM block keeps its iteration state (0: LDS + registers, 1: the factor's LDS part from the workspace,
+// 3: long horizons), see agent_program in dsqp_program.h
 // SPLIT: two specialised lanes per timestep (row waves + solver waves)
 // LDS carve of one agent (see Shm); `lds` is the workgroup's dynamic LDS.  Every array starts 16-byte aligned (even
 // strides) and says so, which lets the compiler use ds_read_b128 / ds_write_b128 on the lane-major arrays.
@@ -44,7 +44,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
     sh.lohi = aligned16(rest);
     sh.carry2 = sh.lohi;
     rest = sh.lohi + 22 * st;
-    if constexpr (MODE < 2) {
+    if constexpr (MODE == 0) {
       sh.fx = aligned16(rest);
       rest = sh.fx + 34 * st;
     } else {
@@ -61,13 +61,13 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   sh.tvec = aligned16(sh.bcast + 32);
   sh.tinv = aligned16(sh.tvec + 2 * TAIL_N);
   rest = sh.tinv + TAIL_N * 38;
-  if constexpr (MODE != 0) {
-    sh.pc = B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes;
-    sh.prow = nullptr;
-  } else {
+  sh.pcg = B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes;
+  if constexpr (MODE == 0) {   // only used by agents with AgentDesc::rows_lds (the launch sized the LDS for them)
     const int n_pc_pad = 2 * ((3 * ad_n_planes + 1) >> 1);
-    sh.pc = rest;
+    sh.pc = aligned16(rest);
     sh.prow = aligned16(sh.pc + n_pc_pad);
+  } else {
+    sh.pc = sh.prow = nullptr;
   }
   double* fac_global = B.fac_ws + ad_fac_off;
   sh.facE = fac_global;

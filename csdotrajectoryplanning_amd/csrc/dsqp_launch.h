@@ -17,10 +17,10 @@ struct LaunchGroup {
   int* queue = nullptr;       // device counter of the group's agent queue (persistent workgroups)
   int primary = 0, elastic = 0;   // workgroups of the first launch (the group's share of the CUs) and of the second one
 };
-size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode);   // LDS working set of one agent
+size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds);   // LDS working set of one agent
 size_t dsqp_lds_capacity();                                        // dynamic LDS one workgroup may ask for
-// kernel class of one agent: returns the workgroup size and sets the residency mode
-int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode);
+// kernel class of one agent: returns the workgroup size, sets the residency mode and whether the rows' state fits LDS
+int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds);
 // Launches `workgroups` persistent workgroups that drain the group's queue (g.queue must have been zeroed on a stream
 // this launch is ordered after); several launches may share one queue.
 hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream);

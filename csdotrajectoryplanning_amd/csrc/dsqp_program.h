@@ -45,6 +45,7 @@ __device__ __forceinline__ int csdo_opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+#define csdo_keep(v) csdo_opaque(v)   // a loaded value the compiler must not re-load (rematerialise) at its uses
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = csdo_opaque((int)threadIdx.x); t < Nt)
 // ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
 #define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
@@ -90,6 +91,7 @@ __device__ __forceinline__ int csdo_opaque(int v) {
 #define CSDO_PHASE(k) ((void)0)
 #endif
 #elif defined(CSDO_LANE_MODE_SERIAL)
+#define csdo_keep(v) (v)
 #define CSDO_FN inline
 #define CSDO_NOINLINE inline
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)
@@ -222,6 +224,7 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
 struct SolvRegs {           // solver lane of timestep t: BCR node t, both couplings in registers during an ADMM block
   double b[6];              // rhs -> BCR work vector -> x_tilde
   double el[36];            // F_l = Sinv E_l: coupling to the left neighbour at this node's elimination level
+  int ts0, ts1;             // plane range of this timestep (CSR offsets), for the rhs assembly
   double er[ER_REG];        // F_r = E_r Sinv: coupling to the right neighbour, first ER_REG entries (the rest: LDS, Shm::fx;
 };                          //                                                              MODE 3: all from the workspace)                          // (the pivot inverse, only needed in the forward sweep, sits in LDS: with it the lane would
                             //  hold 198 of its 256 registers and the compiler spills a third of the factor to scratch)
@@ -280,8 +283,10 @@ struct Shm {
   double* bcast;    // [32] block-wide results
   double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
   double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
-  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs (LDS; workspace in MODE 3)
-  double* prow;     // [K][10] MODE 0: duals and slacks (y[4], z[4]) of a plane's four inter-vehicle rows during an ADMM block
+  double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs, LDS copy (agents whose planes fit: rows_lds)
+  double* pcg;      // [K][3]  the same in the workspace (all other agents)
+  double* prow;     // [K][10] rows_lds: duals, slacks (y[4], z[4]) and timestep of a plane's four inter-vehicle rows during
+                    //              an ADMM block
   int stride;
 };
 
@@ -688,13 +693,13 @@ CSDO_FN double rho_row(const LaneState& S, double rho, double rho_eq) {
   else return (S.eqmask & (1u << I)) ? rho_eq : rho;
 }
 
-// MODE: where the iteration state of an ADMM block lives, chosen per agent by its working set (dsqp_kernel.hip).  Both
+// MODE: where the iteration state of an ADMM block lives, chosen per agent by its working set (dsqp_kernel.hip).  The
 // coupling F_l and two thirds of F_r of a BCR node (60 doubles) sit in its solver lane's REGISTERS in modes 0 and 1.
-//   0  LDS: exchange vectors, bounds of the home rows, the rest of the factor (33 doubles), duals / slacks of the
-//      inter-vehicle rows and their rhs shares (80 doubles per timestep + 13 per plane)
-//   1  as 0, but the inter-vehicle rows' state and rhs shares stay in the L2-resident workspace (agents with very many
-//      planes; 80 doubles per timestep)
-//   2  as 1, and the third of the factor that is not in registers comes from the workspace (horizons 235..256; 46)
+//   0  LDS: exchange vectors, bounds of the home rows, the rest of the factor (80 doubles per timestep); per agent
+//      (AgentDesc::rows_lds, a run-time flag so that one kernel and one queue serve both kinds) also the duals / slacks of
+//      the inter-vehicle rows and their rhs shares (13 doubles per plane) - otherwise those stay in the L2-resident
+//      workspace
+//   1  the third of the factor that is not in registers comes from the workspace too (horizons 235..256; 46 per timestep)
 //   3  horizons beyond 256 (1024 threads, 128 registers per lane): factor, bounds and rows from the workspace; LDS only
 //      holds the exchange vectors (30 doubles per timestep)
 template <int ROLE, int MODE, class RowStore, class SolvStore>

@@ -15,8 +15,8 @@ namespace csdo {
 #define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
 // F_r of node t: the solver lane's registers for the first ER_REG entries, LDS for the rest and for the pivot inverse;
 // everything from the workspace for long horizons
-#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 2 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t))))
-#define SINV(k, t) (MODE >= 2 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
+#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t))))
+#define SINV(k, t) (MODE >= 1 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 #define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 #define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 
@@ -712,7 +712,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     };
 
     // ============================================================== BCR solve on the solver lanes.
-    // In: rhs of lane t in sh.vec[t] (written by the row lane).  Out: x_tilde in V.b and sh.vec[t].
+    // In: rhs of node t in V.b (assembled by the solver lane).  Out: x_tilde in V.b and sh.vec[t].
     // Coupling blocks and pivot inverses come from registers: the only LDS traffic is the 6-vectors.
     auto solve = [&]() __attribute__((always_inline)) {
       CSDO_MARK("solve_begin");
@@ -721,10 +721,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_SYNC();
       return;
 #endif
-      CSDO_SLANES(t) {
-        SolvRegs& V = CSDO_SS(t);
-        CSDO_FOR(k, 6, { V.b[k] = SH(vec, k, t); });
-      }
       for (int h = 1; h < h_tail; h <<= 1) {
         const int m2 = 2 * h - 1;
         CSDO_SLANES(t) {
@@ -898,7 +894,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     auto primal_infeasible = [&](const double eps_pinf) __attribute__((always_inline)) -> bool {
       CSDO_MARK("pinf_begin");
       CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
+        const unsigned act_ = (unsigned)WS(W_ACT, t);
         double dy[NROW], lo_[NROW], hi_[NROW], ee[NROW];
         CSDO_FOR(i, NROW, {
           dy[i] = WS(C_DY + i, t);
@@ -908,7 +904,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         });
         double nmax = 0.0, acc = 0.0;
         CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
+          if (act_ & (1u << i)) {
             double dyi = dy[i];
             if (hi_[i] > OSQP_INFTY * MIN_SCALING) {
               if (lo_[i] < -OSQP_INFTY * MIN_SCALING) dyi = 0.0;
@@ -942,20 +938,21 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       if (!(r_sum[1] < -eps_pinf * norm_dy)) return false;
       // || Dinv A' dy ||
       CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 4, { SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * WS(C_DY + k, t) : 0.0; });
+        const unsigned act_ = (unsigned)WS(W_ACT, t);
+        CSDO_FOR(k, 4, { SH(carry, k, t) = (act_ & (1u << k)) ? WS(W_CN + k, t) * WS(C_DY + k, t) : 0.0; });
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
+        const unsigned act_ = (unsigned)WS(W_ACT, t);
+        const int ncols_ = (t < Nm) ? 6 : 4;
         double dy[NROW];
         CSDO_FOR(i, NROW, { dy[i] = WS(C_DY + i, t); });
         double v[6] = {0, 0, 0, 0, 0, 0};
         if (t > 0) CSDO_FOR(k, 4, { v[k] = SH(carry, k, t - 1); });
         CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
+          if (act_ & (1u << i)) {
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(S.c[i][s], dy[i], v[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) v[row_col(i, s)] = fma(WS(W_C + 3 * i + s, t), dy[i], v[row_col(i, s)]);
             });
           }
         });
@@ -967,7 +964,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         double nmax = 0.0;
         CSDO_FOR(j, 6, {
-          if (j < S.ncols) nmax = dmax(nmax, fabs((1.0 / WS(C_D + j, t)) * v[j]));
+          if (j < ncols_) nmax = dmax(nmax, fabs((1.0 / WS(C_D + j, t)) * v[j]));
         });
         const double part[1] = {nmax};
         red_put<1>(sh, t, part);
@@ -1014,23 +1011,28 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     };
 
     // update_info (auxil.c): residuals of the current (x, z, y), unscaled for the termination test and scaled for
-    // adapt_rho.  Always called right after an ADMM block, while the row lanes still hold c, cn, y, z, x in registers;
-    // only the Ruiz scalings and the objective come from the workspace (one batch of loads).
+    // adapt_rho.  Always called right after an ADMM block has written its iterate back to the workspace; everything is
+    // read from there.
     auto update_info = [&]() __attribute__((always_inline)) {
       CSDO_MARK("info_begin");
       CSDO_PHASE(10);
       CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 5, { SH(carry2, k, t) = S.x[k]; });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
-        CSDO_FOR(k, 4, {                                  // to t+1: A'y share of the kinematic rows
-          SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * S.y[k] : 0.0;
+        const unsigned act_ = (unsigned)WS(W_ACT, t);
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = WS(W_X + k, t); });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
+        CSDO_FOR(k, 4, {                                          // to t+1: A'y share of the kinematic rows
+          SH(carry, k, t) = (act_ & (1u << k)) ? WS(W_CN + k, t) * WS(W_Yv + k, t) : 0.0;
         });
-        SH(carry, 4, t) = S.x[4];
+        SH(carry, 4, t) = WS(W_X + 4, t);
         SH(carry, 5, t) = WS(W_P + 2, t);
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
+        // the iterate and the coefficients come from the workspace (the block has just written x, y, z back), into
+        // temporaries of this phase: the row lanes' hot register cache is dead here
+        const unsigned act_ = (unsigned)WS(W_ACT, t);
+        const int ncols_ = (t < Nm) ? 6 : 4;
+        double x_[6];
+        CSDO_FOR(j, 6, { x_[j] = WS(W_X + j, t); });
         double einv[NROW], dinv[6];
         CSDO_FOR(i, NROW, { einv[i] = WS(C_E + i, t); });
         CSDO_FOR(j, 6, { dinv[j] = WS(C_D + j, t); });
@@ -1049,13 +1051,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         double p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
+          if (act_ & (1u << i)) {
+            double ci[3] = {0, 0, 0};
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) ci[s] = WS(W_C + 3 * i + s, t);
+            });
             double ax = 0.0;
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) ax = fma(S.c[i][s], S.x[row_col(i, s)], ax);
+              if constexpr (row_col(i, s) >= 0) ax = fma(ci[s], x_[row_col(i, s)], ax);
             });
-            if constexpr (i < 4) ax = fma(S.cn[i], xn[i], ax);
-            const double zi = S.z[i], yi = S.y[i];
+            if constexpr (i < 4) ax = fma(WS(W_CN + i, t), xn[i], ax);
+            const double zi = WS(W_Zv + i, t), yi = WS(W_Yv + i, t);
             const double ei = 1.0 / einv[i];
             const double res = ax - zi;
             p[0] = dmax(p[0], fabs(ei * res));
@@ -1065,7 +1071,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             p[4] = dmax(p[4], fabs(zi));
             p[5] = dmax(p[5], fabs(ax));
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(S.c[i][s], yi, Aty[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(ci[s], yi, Aty[row_col(i, s)]);
             });
           }
         });
@@ -1080,7 +1086,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             ee[q] = ROW(4 * k + q, R_E);
           });
           CSDO_FOR(q, 4, {
-            const double ax = (ca[q] * S.x[0] + cb[q] * S.x[1]) + cy[q] * S.x[2];
+            const double ax = (ca[q] * x_[0] + cb[q] * x_[1]) + cy[q] * x_[2];
             const double ei = 1.0 / ee[q];
             const double res = ax - zz[q];
             p[0] = dmax(p[0], fabs(ei * res));
@@ -1096,11 +1102,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         double Px[6] = {0, 0, 0, 0, 0, 0};
         if (t < Nm) {
-          Px[4] = (pvv * S.x[4] + pvn * vn) + pvn_left * vp;
-          Px[5] = pww * S.x[5];
+          Px[4] = (pvv * x_[4] + pvn * vn) + pvn_left * vp;
+          Px[5] = pww * x_[5];
         }
         CSDO_FOR(j, 6, {
-          if (j < S.ncols) {
+          if (j < ncols_) {
             const double dj = 1.0 / dinv[j];
             const double dr = (0.0 + Px[j]) + Aty[j];
             p[6] = dmax(p[6], fabs(dj * dr));
@@ -1118,31 +1124,43 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     };
 
     // ---- the ADMM loop runs in blocks that end where osqp_solve would look at the iterate (termination check,
-    // rho adaptation, iteration cap).  Inside a block only register state and the LDS 6-vectors are touched, plus the
-    // inter-vehicle rows of the solver lanes.
+    // rho adaptation, iteration cap).  Inside a block only register state and LDS are touched (agents whose planes do
+    // not fit keep the inter-vehicle rows' state in the L2-resident workspace).
     // Inter-vehicle rows are spread evenly over ALL solver threads (also those beyond Nt), plane by plane (thread l takes
-    // planes l, l + nthr, ...: coalesced 32-byte field loads, at most ceil(K / nthr) planes per thread whatever their
-    // timesteps).  `plane_pass<UPDATE>`
+    // planes l, l + nthr, ...; at most ceil(K / nthr) planes per thread whatever their timesteps).  `plane_pass`
     // optionally applies the z / y update with x_tilde of the plane's timestep (read from sh.vec) and leaves the
-    // plane's share of A'(rho z - y) in pc[p][0..2]; the row lane of that timestep adds its planes' shares to its rhs.
+    // plane's share of A'(rho z - y) in pc[p][0..2]; the solver lane of that timestep adds its planes' shares to its rhs.
+    // ROWS_LDS: duals, slacks, the plane's timestep and the shares live in LDS for the block (Shm::prow, Shm::pc); the
+    // rows' coefficients and bounds (constant over a QP) are read from the workspace through the vector cache.
     const int K_planes = ad.n_planes;
-#define PC(k, p) sh.pc[(p) * 3 + (k)]
-    auto plane_pass = [&](auto update_c, auto keep_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
+    const bool rows_lds = (MODE == 0) && (uniform_i32(ad.rows_lds) != 0);
+#define PC_L(k, p) sh.pc[(p) * 3 + (k)]
+#define PC_G(k, p) sh.pcg[(p) * 3 + (k)]
+#define PROW(f, p) sh.prow[(p) * LD_prow + (f)]   // f: 0..3 y, 4..7 z, 8 timestep
+    auto plane_pass = [&](auto update_c, auto keep_c, auto lds_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
       constexpr bool KEEP = decltype(keep_c)::value;
+      constexpr bool ROWS_LDS = decltype(lds_c)::value;
       const double rinv = uniform_f64(1.0 / rho_now);
       for (int p = lane; p < K_planes; p += nthr) {
         double zz[4], yy[4], ca[4], cb[4], cy[4], uu[4], xt[3] = {0, 0, 0};
         CSDO_FOR(q, 4, {
-          zz[q] = ROW(4 * p + q, R_Z);
-          yy[q] = ROW(4 * p + q, R_Y);
+          if constexpr (ROWS_LDS) {
+            yy[q] = PROW(q, p);
+            zz[q] = PROW(4 + q, p);
+          } else {
+            zz[q] = ROW(4 * p + q, R_Z);
+            yy[q] = ROW(4 * p + q, R_Y);
+          }
           ca[q] = ROW(4 * p + q, R_CA);
           cb[q] = ROW(4 * p + q, R_CB);
           cy[q] = ROW(4 * p + q, R_CY);
           if constexpr (UPDATE) uu[q] = ROW(4 * p + q, R_U);
         });
         if constexpr (UPDATE) {
-          const int tp = planes[p].t;
+          int tp;
+          if constexpr (ROWS_LDS) tp = (int)PROW(8, p);
+          else tp = planes[p].t;
           CSDO_FOR(k, 3, { xt[k] = SH(vec, k, tp); });
         }
         double ic[3] = {0, 0, 0};
@@ -1156,15 +1174,21 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             if constexpr (KEEP) ROW(4 * p + q, R_DY) = d;
             yq = yq + d;
             zq = zn;
-            ROW(4 * p + q, R_Y) = yq;
-            ROW(4 * p + q, R_Z) = zq;
+            if constexpr (ROWS_LDS) {
+              PROW(q, p) = yq;
+              PROW(4 + q, p) = zq;
+            } else {
+              ROW(4 * p + q, R_Y) = yq;
+              ROW(4 * p + q, R_Z) = zq;
+            }
           }
           const double g = fma(rho_now, zq, -yq);
           ic[0] = fma(ca[q], g, ic[0]);
           ic[1] = fma(cb[q], g, ic[1]);
           ic[2] = fma(cy[q], g, ic[2]);
         });
-        CSDO_FOR(k, 3, { PC(k, p) = ic[k]; });
+        if constexpr (ROWS_LDS) CSDO_FOR(k, 3, { PC_L(k, p) = ic[k]; });
+        else CSDO_FOR(k, 3, { PC_G(k, p) = ic[k]; });
       }
     };
 
@@ -1176,23 +1200,46 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       if (chk) stop = osqp_min_i(stop, (iter / chk + 1) * chk);
       if (P.adaptive_rho_interval) stop = osqp_min_i(stop, (iter / P.adaptive_rho_interval + 1) * P.adaptive_rho_interval);
       CSDO_PHASE(12);
-      CSDO_LANES(t) {  // load the row-lane cache
-        LaneState& S = CSDO_LS(t);
+      const double rho_eq = uniform_f64(RHO_EQ_OVER_RHO_INEQ * rho), rinv_in = uniform_f64(1.0 / rho),
+                   rinv_eq = uniform_f64(1.0 / rho_eq);
+      // The row lane's own share of the next rhs of the reduced system, sigma x + A'(rho z - y) over its home rows (q = 0),
+      // and the kinematic rows' share for t+1: computed where x, z, y have just been updated (registers), so that the
+      // solve can start right behind the update's barrier.
+      auto publish_rhs = [&](LaneState& S, const int t) __attribute__((always_inline)) {
+        double r6[6];
+        CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
+        double kin[4] = {0, 0, 0, 0};
         CSDO_FOR(i, NROW, {
-          CSDO_FOR(s, 3, {
-            if constexpr (row_col(i, s) >= 0) S.c[i][s] = WS(W_C + 3 * i + s, t);
-          });
-          // bounds are read once per iteration: LDS, not registers (layout: Shm::lohi)
-          if constexpr (MODE != 3) {
-            if constexpr (i < 7) SH(lohi, i, t) = WS(W_LO + i, t);
-            if constexpr (i >= 7 && i < 13) {
-              SH(lohi, i, t) = WS(W_LO + i, t);
-              SH(lohi, i + 6, t) = WS(W_HI + i, t);
-            }
-            if constexpr (i >= 13) SH(lohi, i + 6, t) = WS(W_HI + i, t);
+          if (S.act & (1u << i)) {
+            const double g = fma(rho_row<i>(S, rho, rho_eq), S.z[i], -S.y[i]);
+            CSDO_FOR(s_, 3, {
+              if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(S.c[i][s_], g, r6[row_col(i, s_)]);
+            });
+            if constexpr (i < 4) kin[i] = S.cn[i] * g;
           }
+        });
+        CSDO_FOR(j, 6, { SH(rhs, j, t) = r6[j]; });
+        CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
+      };
+      CSDO_LANES(t) {  // load the row-lane cache, in stages: with every load of it in flight at once (some 90 doubles) this
+        // is the row role's register peak, and what the allocator spills for it stays spilled in the iterations
+        LaneState& S = CSDO_LS(t);
+        // bounds are read once per iteration: LDS, not registers (layout: Shm::lohi)
+        if constexpr (MODE != 3) {
+          CSDO_FOR(i, 13, { SH(lohi, i, t) = WS(W_LO + i, t); });
+          CSDO_STAGE();
+          CSDO_FOR(i, 9, { SH(lohi, 13 + i, t) = WS(W_HI + 7 + i, t); });
+          CSDO_STAGE();
+        }
+        CSDO_FOR(i, NROW, {
           S.y[i] = WS(W_Yv + i, t);
           S.z[i] = WS(W_Zv + i, t);
+        });
+        CSDO_STAGE();
+        CSDO_FOR(i, NROW, {
+          CSDO_FOR(s_, 3, {
+            if constexpr (row_col(i, s_) >= 0) S.c[i][s_] = WS(W_C + 3 * i + s_, t);
+          });
         });
         CSDO_FOR(i, 4, { S.cn[i] = WS(W_CN + i, t); });
         CSDO_FOR(j, 6, { S.x[j] = WS(W_X + j, t); });
@@ -1200,57 +1247,63 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         S.eqmask = (unsigned)WS(W_EQ, t);
         S.loosemask = (unsigned)WS(W_LOOSE, t);
         S.ncols = (t < Nm) ? 6 : 4;
-        const double rho_eq0 = uniform_f64(RHO_EQ_OVER_RHO_INEQ * rho);
-        CSDO_FOR(k, 4, {
-          SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq0, S.z[k], -S.y[k]) : 0.0;
-        });
+        CSDO_STAGE();
+        publish_rhs(S, t);
       }
       CSDO_SLANES(t) {  // load the solver-lane cache: 60 doubles of the node's factor in registers, 33 in LDS
         SolvRegs& V = CSDO_SS(t);
         CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
         if constexpr (MODE != 3) {
           CSDO_FOR(k, ER_REG, { V.er[k] = FE(36 + k, t); });
-          if constexpr (MODE < 2) {
+          if constexpr (MODE == 0) {
             CSDO_FOR(k, FX_ER, { SH(fx, k, t) = FE(36 + ER_REG + k, t); });
             CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
           }
         }
+        V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
+        V.ts1 = csdo_keep(tstart[t + 1]);
       }
-      CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, l, nthr, rho); }
+      if (rows_lds) {   // the inter-vehicle rows' duals, slacks and timesteps move into LDS for the block
+        CSDO_STHREADS(l, nthr) {
+          for (int p = l; p < K_planes; p += nthr) {
+            CSDO_FOR(q, 4, {
+              PROW(q, p) = ROW(4 * p + q, R_Y);
+              PROW(4 + q, p) = ROW(4 * p + q, R_Z);
+            });
+            PROW(8, p) = (double)planes[p].t;
+          }
+          plane_pass(std::false_type{}, std::false_type{}, std::true_type{}, l, nthr, rho);
+        }
+      } else {
+        CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, std::false_type{}, l, nthr, rho); }
+      }
       CSDO_SYNC();
-      const double rho_eq = uniform_f64(RHO_EQ_OVER_RHO_INEQ * rho), rinv_in = uniform_f64(1.0 / rho),
-                   rinv_eq = uniform_f64(1.0 / rho_eq);
       auto iteration = [&](auto keep_c) __attribute__((always_inline)) {
         constexpr bool keep_dy = decltype(keep_c)::value;   // only the last iteration of a block records delta_y
-        CSDO_PHASE(6);
-        // ---- rhs of the reduced system: sigma x + A'(rho z - y)   (q = 0)
-        // (the kinematic rows' share for t+1, sh.carry, was left by the previous update / the block's load)
+        // ---- rhs of the reduced system: the solver lane adds the kinematic share of t-1 and its planes' shares to what
+        // its row lane left in sh.rhs (previous update / block load); no row-lane phase, no barrier in between
         CSDO_MARK("rhs");
-        CSDO_LANES_HOT(t) {
-          LaneState& S = CSDO_LS(t);
+        CSDO_SLANES_HOT(t) {
+          SolvRegs& V = CSDO_SS(t);
           double r6[6];
-          CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
+          CSDO_FOR(j, 6, { r6[j] = SH(rhs, j, t); });
           if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
-          CSDO_FOR(i, NROW, {
-            if (S.act & (1u << i)) {
-              const double g = fma(rho_row<i>(S, rho, rho_eq), S.z[i], -S.y[i]);
-              CSDO_FOR(s, 3, {
-                if constexpr (row_col(i, s) >= 0) r6[row_col(i, s)] = fma(S.c[i][s], g, r6[row_col(i, s)]);
-              });
-            }
-          });
-          for (int p = tstart[t]; p < tstart[t + 1]; ++p)      // inter-vehicle rows: per-plane shares from the solver lanes
-            CSDO_FOR(k, 3, { r6[k] += PC(k, p); });
-          CSDO_FOR(j, 6, { SH(vec, j, t) = r6[j]; });
+          if (rows_lds) {
+            for (int p = V.ts0; p < V.ts1; ++p) CSDO_FOR(k, 3, { r6[k] += PC_L(k, p); });
+          } else {
+            for (int p = V.ts0; p < V.ts1; ++p) CSDO_FOR(k, 3, { r6[k] += PC_G(k, p); });
+          }
+          CSDO_FOR(j, 6, { V.b[j] = r6[j]; });
         }
-        CSDO_SYNC();
         solve();
         CSDO_PHASE(9);
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");
 #if !defined(CSDO_ABL_NOPLANES)
-        CSDO_STHREADS_HOT(l, nthr) {  // inter-vehicle rows, concurrently with the row lanes below
-          plane_pass(std::true_type{}, keep_c, l, nthr, rho);
+        if (rows_lds) {   // inter-vehicle rows, concurrently with the row lanes below
+          CSDO_STHREADS_HOT(l, nthr) { plane_pass(std::true_type{}, keep_c, std::true_type{}, l, nthr, rho); }
+        } else {
+          CSDO_STHREADS_HOT(l, nthr) { plane_pass(std::true_type{}, keep_c, std::false_type{}, l, nthr, rho); }
         }
 #endif
         CSDO_LANES_HOT(t) {
@@ -1269,8 +1322,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(i, NROW, {
             if (S.act & (1u << i)) {
               double zt = 0.0;
-              CSDO_FOR(s, 3, {
-                if constexpr (row_col(i, s) >= 0) zt = fma(S.c[i][s], xt[row_col(i, s)], zt);
+              CSDO_FOR(s_, 3, {
+                if constexpr (row_col(i, s_) >= 0) zt = fma(S.c[i][s_], xt[row_col(i, s_)], zt);
               });
               if constexpr (i < 4) zt = fma(S.cn[i], xn[i], zt);
               const double rh = rho_row<i>(S, rho, rho_eq);
@@ -1297,10 +1350,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(j, 6, {
             if (j < S.ncols) S.x[j] = alpha * xt[j] + (1.0 - alpha) * S.x[j];
           });
-          // hand the kinematic rows' share of the next rhs to t+1 now: saves the next iteration a barrier
-          CSDO_FOR(k, 4, {
-            SH(carry, k, t) = (S.act & (1u << k)) ? S.cn[k] * fma(rho_eq, S.z[k], -S.y[k]) : 0.0;
-          });
+          publish_rhs(S, t);   // own share of the next rhs + the kinematic rows' share for t+1
         }
         CSDO_SYNC();
       };
@@ -1318,6 +1368,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           WS(W_Zv + i, t) = S.z[i];
         });
         CSDO_FOR(j, 6, { WS(W_X + j, t) = S.x[j]; });
+      }
+      if (rows_lds) {   // ... and the inter-vehicle rows' duals and slacks go back to the workspace for the cold phases
+        CSDO_STHREADS(l, nthr) {
+          for (int p = l; p < K_planes; p += nthr) {
+            CSDO_FOR(q, 4, {
+              ROW(4 * p + q, R_Y) = PROW(q, p);
+              ROW(4 * p + q, R_Z) = PROW(4 + q, p);
+            });
+          }
+        }
       }
       CSDO_SYNC();
 
@@ -1507,7 +1567,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   out.admm_iters = admm_total;
   out.last_status = status;
 #undef ROW
-#undef PC
+#undef PC_L
+#undef PC_G
+#undef PROW
 }
 
 #undef SH

@@ -13,14 +13,17 @@
 
 using namespace csdo;
 
-// mode: residency of the ADMM blocks' state (agent_program in dsqp_program.h): 0 .. 3; all give identical results
+// mode: residency of the ADMM blocks' state (agent_program in dsqp_program.h): 0 (10: with the rows' state in LDS), 1, 3; all give identical results
 // n_threads > 1: agents are solved concurrently (each has its own workspace slice and its own "LDS"), results unchanged
 extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode,
                                        int n_threads) {
-  if (mode < 0 || mode > 3) return CSDO_EINVAL;
+  if (mode != 0 && mode != 1 && mode != 3 && mode != 10) return CSDO_EINVAL;   // 10: mode 0 with the rows' state in "LDS"
+  const bool rows_lds = mode == 10;
+  if (rows_lds) mode = 0;
   HostBatch hb;
   const int rc = pack_worlds(worlds, n_worlds, hb);
   if (rc != CSDO_OK) return rc;
+  for (auto& ad : hb.agents) ad.rows_lds = rows_lds ? 1 : 0;
   const int Na = (int)hb.agents.size();
   std::vector<double> rows_ws((size_t)std::max<int64_t>(hb.rows_total, 1) * ROWS_WS_STRIDE, 0.0);
   std::vector<double> fac_ws((size_t)hb.fac_total, 0.0);
@@ -49,9 +52,11 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
   auto solve_agent = [&](const int a) {
     const AgentDesc& ad = hb.agents[a];
     const int st = fac_stride(ad.Nt);
-    // the same carve as dsqp_kernel_body.h (modes 0, 1: bounds in "LDS"; 0: the inter-vehicle rows' state too; 3: lean)
+    // the same carve as dsqp_kernel_body.h (mode 0: bounds + the factor's LDS part in "LDS", rows' state too when
+    // AgentDesc::rows_lds; 1: without the factor part; 3: lean)
     std::vector<double> lds((size_t)80 * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N + TAIL_N * 38 +
                             (size_t)(3 + LD_prow) * hb.max_planes + 4, 0.0);
+    std::vector<double> pc_ws((size_t)3 * hb.max_planes + 1, 0.0);
     Shm sh{};
     sh.stride = st;
     sh.vec = lds.data();
@@ -66,7 +71,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
       sh.lohi = rest;
       sh.carry2 = sh.lohi;
       rest = sh.lohi + 22 * st;
-      if (mode < 2) {
+      if (mode == 0) {
         sh.fx = rest;
         rest = sh.fx + 34 * st;
       }
@@ -78,12 +83,10 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     sh.bcast = sh.obs + ((3 * hb.max_obs + 1) & ~1);
     sh.tvec = sh.bcast + 32;
     sh.tinv = sh.tvec + 2 * TAIL_N;
-    sh.pc = sh.tinv + TAIL_N * 38;
-    sh.prow = mode == 0 ? sh.pc + ((3 * hb.max_planes + 1) & ~1) : nullptr;
-    std::vector<double> pc_ws;
-    if (mode != 0) {
-      pc_ws.assign((size_t)3 * hb.max_planes + 1, 0.0);
-      sh.pc = pc_ws.data();
+    sh.pcg = pc_ws.data();
+    if (mode == 0) {
+      sh.pc = sh.tinv + TAIL_N * 38;
+      sh.prow = sh.pc + ((3 * hb.max_planes + 1) & ~1);
     }
     sh.facE = fac_ws.data() + ad.fac_off;
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;
@@ -93,7 +96,6 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     ProgramOut po{};
     if (mode == 0) agent_program<ROLE_BOTH, 0>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 1) agent_program<ROLE_BOTH, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-    else if (mode == 2) agent_program<ROLE_BOTH, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else agent_program<ROLE_BOTH, 3>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     sqp[a] = po.sqp_iters;
     admm[a] = po.admm_iters;

@@ -85,18 +85,21 @@ def test_gpu_is_deterministic_and_handle_is_reusable(gpu_handle, veh_parm):
 
 
 def test_gpu_lds_residency_modes_are_bit_identical(gpu_handle, veh_parm):
-    """Agents whose working set exceeds LDS keep the inter-vehicle rows' state in the workspace (mode 1): same doubles,
-    same arithmetic, so bit-identical results.  (Mode 3, horizons beyond 256, is covered by the long-horizon test.)"""
+    """Where an ADMM block keeps its state only changes where the same doubles are read from: with the inter-vehicle rows'
+    duals / slacks in the workspace instead of LDS (knob 1) and with the LDS part of the factor read from the workspace
+    (knob 2, the 512-thread class's mode 1) the results are bit-identical.  (Mode 3: the long-horizon test.)"""
     veh, parm = veh_parm
     w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     w2, _ = helpers.load_golden("map100_agents0to3.npz", veh, parm)      # Nt = 169: 512-thread class
     ref = gpu_handle.solve_batch([w1, w2])
+    assert all(g["residency_mode"] == 0 for g in gpu_handle.launch_groups())
     try:
-        for mode in (1, 2):
-            gpu_handle.set_min_residency_mode(mode)
+        for knob in (1, 2):
+            gpu_handle.set_min_residency_mode(knob)
             got = gpu_handle.solve_batch([w1, w2])
             groups = gpu_handle.launch_groups()
-            assert all(g["residency_mode"] >= min(mode, 2 if g["threads"] == 512 else 1) for g in groups) and sum(g["n_agents"] for g in groups) == w1.Na + w2.Na
+            assert sum(g["n_agents"] for g in groups) == w1.Na + w2.Na
+            assert all(g["residency_mode"] == (1 if (knob == 2 and g["threads"] == 512) else 0) for g in groups)
             for r, g in zip(ref, got):
                 assert np.array_equal(r.solutions, g.solutions) and np.array_equal(r.corridors, g.corridors)
                 assert np.array_equal(r.admm_iters, g.admm_iters) and np.array_equal(r.last_status, g.last_status)

@@ -53,6 +53,13 @@ class Result(C.Structure):
                 ("t_max_individual", C.c_double), ("agent_seconds", c_double_p)]
 
 
+class Validation(C.Structure):
+    """csdo_validation (include/csdo_dsqp.h)."""
+    _fields_ = [("vehicle_collisions", C.c_int64), ("obstacle_collisions", C.c_int64), ("out_of_map", C.c_int64),
+                ("first_vehicle", C.c_int32 * 3), ("first_obstacle", C.c_int32 * 3),
+                ("min_obstacle_clearance", C.c_double)]
+
+
 class BridgeOut(C.Structure):
     _fields_ = [("Na", C.c_int32), ("Nt", C.c_int32), ("x0_bar", c_double_p), ("plane_off", c_int32_p),
                 ("planes", C.POINTER(Plane)), ("n_pairs", C.c_int32), ("initial_inter_legal", C.c_int32),
@@ -82,6 +89,6 @@ EXPORTED_SYMBOLS = (
     "csdo_dsqp_create", "csdo_dsqp_destroy", "csdo_dsqp_solve", "csdo_dsqp_solve_batch", "csdo_dsqp_upload",
     "csdo_dsqp_run", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_last_transfer_seconds", "csdo_dsqp_launch_groups", "csdo_dsqp_agent_groups", "csdo_dsqp_set_min_residency_mode",
     "csdo_dsqp_device_solutions",
-    "csdo_preprocess", "csdo_bridge_free", "csdo_generate_boxes", "csdo_vehicle_default",
+    "csdo_preprocess", "csdo_preprocess_device", "csdo_bridge_free", "csdo_validate", "csdo_generate_boxes", "csdo_vehicle_default",
     "csdo_qp_parm_default", "csdo_backend_name",
 )

@@ -89,8 +89,9 @@ inline double sq(float a, float b) {  // pow(float - float, 2): float difference
 
 }  // namespace
 
-int bridge_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
-                      const double* goals, const csdo_vehicle* vehp, const csdo_qp_parm* parm, csdo_bridge_out* out) {
+int bridge_interpolate(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                       const double* goals, const csdo_vehicle* vehp, const csdo_qp_parm* parm, csdo_bridge_out* out,
+                       BridgeCentres& C) {
   if (!states || !actions || !path_off || !goals || !vehp || !parm || !out || Na < 1) return CSDO_EINVAL;
   std::memset(out, 0, sizeof(*out));
   const Veh v{(float)vehp->r, (float)vehp->LF, (float)vehp->LB, (float)vehp->car_width,
@@ -163,7 +164,10 @@ int bridge_preprocess(const double* states, const int32_t* actions, const int32_
 
   // ---- float disc centres and rectangle centres of every (agent, t) (State ctor, motion_planning.h:115-132) ----
   const size_t NN = (size_t)Na * Nt;
-  std::vector<float> xf(NN), yf(NN), xr(NN), yr(NN), xc(NN), yc(NN), cs(NN), sn(NN);
+  C.Na = Na;
+  C.Nt = (int)Nt;
+  for (std::vector<float>* a_ : {&C.xf, &C.yf, &C.xr, &C.yr, &C.xc, &C.yc, &C.cs, &C.sn}) a_->assign(NN, 0.f);
+  std::vector<float>&xf = C.xf, &yf = C.yf, &xr = C.xr, &yr = C.yr, &xc = C.xc, &yc = C.yc, &cs = C.cs, &sn = C.sn;
   const float c2r = (v.LF + v.LB) / 2 - v.LB;
   for (size_t k = 0; k < NN; ++k) {
     const double x = out->x0_bar[k * 6], y = out->x0_bar[k * 6 + 1], yaw = out->x0_bar[k * 6 + 2];
@@ -178,8 +182,21 @@ int bridge_preprocess(const double* states, const int32_t* actions, const int32_
     sn[k] = (float)s;
   }
 
+  return CSDO_OK;
+}
+
+// findNeighborPairsByTrustRegion (:12-49) on the float centres: pairs (t, i, j) in that order; false if two rectangles overlap
+bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* vehp, std::vector<int32_t>& pairs) {
+  const Veh v{(float)vehp->r, (float)vehp->LF, (float)vehp->LB, (float)vehp->car_width,
+              (float)vehp->f2x, (float)vehp->r2x, (float)vehp->rv};
+  const int Na = C.Na;
+  const size_t Nt = (size_t)C.Nt;
+  const std::vector<float>&xf = C.xf, &yf = C.yf, &xr = C.xr, &yr = C.yr, &xc = C.xc, &yc = C.yc, &cs = C.cs, &sn = C.sn;
+  csdo_qp_parm parm_{};
+  parm_.r_trust = r_trust;
+  const csdo_qp_parm* parm = &parm_;
+  pairs.clear();
   // ---- neighbour pairs (findNeighborPairsByTrustRegion :12-49), order (t, i, j) ----
-  std::vector<int32_t> pairs;
   bool legal = true;
   const double reach = 2 * std::sqrt(2) * parm->r_trust;
   const float length = v.LF + v.LB, width = v.W;
@@ -209,8 +226,20 @@ int bridge_preprocess(const double* states, const int32_t* actions, const int32_
         if (hit) legal = false;
       }
     }
-  const int n_pairs = (int)(pairs.size() / 3);
 
+  return legal;
+}
+
+// calcEqualInterPlanes (:71-140): per-agent CSR of planes in pair order.  `coef` = precomputed coefficients
+// [n_pairs][24] (agent i's 12 then agent j's 12, e.g. from the device kernel) or null to compute them here.
+int bridge_planes(const BridgeCentres& C, const std::vector<int32_t>& pairs, const csdo_vehicle* vehp, const double* coef,
+                  csdo_bridge_out* out) {
+  const Veh v{(float)vehp->r, (float)vehp->LF, (float)vehp->LB, (float)vehp->car_width,
+              (float)vehp->f2x, (float)vehp->r2x, (float)vehp->rv};
+  const int Na = C.Na;
+  const size_t Nt = (size_t)C.Nt;
+  const std::vector<float>&xf = C.xf, &yf = C.yf, &xr = C.xr, &yr = C.yr;
+  const int n_pairs = (int)(pairs.size() / 3);
   // ---- separating planes (calcEqualInterPlanes :71-140, calcPerpendicular :54-69) ----
   std::vector<int32_t> cnt(Na + 1, 0);
   for (int p = 0; p < n_pairs; ++p) {
@@ -238,6 +267,11 @@ int bridge_preprocess(const double* states, const int32_t* actions, const int32_
     csdo_plane& pi = out->planes[fill[i]++];
     csdo_plane& pj = out->planes[fill[j]++];
     pi.t = pj.t = t;
+    if (coef) {
+      std::memcpy(pi.c, coef + (size_t)p * 24, sizeof(pi.c));
+      std::memcpy(pj.c, coef + (size_t)p * 24 + 12, sizeof(pj.c));
+      continue;
+    }
     for (int own = 0; own < 2; ++own)
       for (int oth = 0; oth < 2; ++oth) {
         const double x1 = Pi[own][0], y1 = Pi[own][1], x2 = Pj[oth][0], y2 = Pj[oth][1];
@@ -256,6 +290,17 @@ int bridge_preprocess(const double* states, const int32_t* actions, const int32_
       }
   }
   out->n_pairs = n_pairs;
+  return CSDO_OK;
+}
+
+int bridge_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                      const double* goals, const csdo_vehicle* vehp, const csdo_qp_parm* parm, csdo_bridge_out* out) {
+  BridgeCentres C;
+  int rc = bridge_interpolate(states, actions, path_off, Na, goals, vehp, parm, out, C);
+  if (rc != CSDO_OK) return rc;
+  std::vector<int32_t> pairs;
+  const bool legal = bridge_pairs(C, parm->r_trust, vehp, pairs);
+  if ((rc = bridge_planes(C, pairs, vehp, nullptr, out)) != CSDO_OK) return rc;
   out->initial_inter_legal = legal ? 1 : 0;
   return CSDO_OK;
 }

@@ -4,9 +4,24 @@
 // O(Na*Nt) interpolation and O(Nt*Na^2) pair search on precomputed float disc centres: host work by design
 // (SURVEY 8a rows a2-a4), it is ~1 ms at 50 agents.
 #pragma once
+#include <vector>
+
 #include "../../include/csdo_dsqp.h"
 
 namespace csdo {
+// float disc / rectangle centres and heading cosines of every (agent, t), as the reference's State constructor stores
+// them (common/motion_planning.h:115-132): the inputs of the neighbour search and of the plane generation
+struct BridgeCentres {
+  int Na = 0, Nt = 0;
+  std::vector<float> xf, yf, xr, yr, xc, yc, cs, sn;   // [Na][Nt]
+};
+// stages of bridge_preprocess (the device path, csdo_preprocess_device, replaces the two O(Nt Na^2) ones)
+int bridge_interpolate(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                       const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out,
+                       BridgeCentres& C);
+bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* veh, std::vector<int32_t>& pairs);
+int bridge_planes(const BridgeCentres& C, const std::vector<int32_t>& pairs, const csdo_vehicle* veh, const double* coef,
+                  csdo_bridge_out* out);
 int bridge_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                       const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
 void bridge_free(csdo_bridge_out* out);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include "../../include/csdo_dsqp.h"
 #include "batch_pack.h"
 #include "bridge_host.h"
+#include "aux_kernels.h"
 #include "dsqp_launch.h"
 
 using namespace csdo;
@@ -85,6 +87,7 @@ struct csdo_handle_s {
   double last_kernel_s = 0.0;
   DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d, queues;
   DevBuf box_pts, box_obs, box_out, box_status;
+  DevBuf k0_centres, k0_counts, k0_offsets, k0_pairs, k0_coef, k0_flag, val_sol, val_obs, val_out;
   DevBuf prof;
   PinnedBuf stage_up, stage_down;   // page-locked staging of the packed inputs / outputs
   double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
@@ -194,7 +197,8 @@ void csdo_dsqp_destroy(csdo_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
                     &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->queues, &h->box_pts,
-                    &h->box_obs, &h->box_out, &h->box_status, &h->prof})
+                    &h->box_obs, &h->box_out, &h->box_status, &h->prof, &h->k0_centres, &h->k0_counts, &h->k0_offsets,
+                    &h->k0_pairs, &h->k0_coef, &h->k0_flag, &h->val_sol, &h->val_obs, &h->val_out})
     b->release();
   h->stage_up.release();
   h->stage_down.release();
@@ -518,6 +522,113 @@ int csdo_preprocess(const double* states, const int32_t* actions, const int32_t*
 }
 
 void csdo_bridge_free(csdo_bridge_out* out) { bridge_free(out); }
+
+// The bridge with its two O(Nt Na^2) stages on the device (aux_kernels.hip): interpolation and float disc centres on the
+// host (O(Na Nt), glibc trigonometry exactly as the host bridge), neighbour search + plane coefficients on the device in
+// the reference's (t, i, j) order, per-agent CSR assembly on the host.  Same outputs as csdo_preprocess, bit for bit.
+int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                           const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out) {
+  if (!h) return CSDO_EINVAL;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  BridgeCentres C;
+  int rc = bridge_interpolate(states, actions, path_off, Na, goals, veh, parm, out, C);
+  if (rc != CSDO_OK) return rc;
+  const int Nt = C.Nt;
+  const size_t NN = (size_t)Na * Nt;
+  auto fail = [&](int code) {
+    bridge_free(out);
+    return code;
+  };
+  if ((rc = h->k0_centres.ensure(8 * NN * sizeof(float))) != CSDO_OK) return fail(rc);
+  if ((rc = h->k0_counts.ensure(NN * sizeof(int))) != CSDO_OK) return fail(rc);
+  if ((rc = h->k0_offsets.ensure((NN + 1) * sizeof(long long))) != CSDO_OK) return fail(rc);
+  if ((rc = h->k0_flag.ensure(sizeof(int))) != CSDO_OK) return fail(rc);
+  hipStream_t s = h->stream;
+  float* base = (float*)h->k0_centres.p;
+  const std::vector<float>* src[8] = {&C.xf, &C.yf, &C.xr, &C.yr, &C.xc, &C.yc, &C.cs, &C.sn};
+  for (int k = 0; k < 8; ++k)
+    if (hipMemcpyAsync(base + k * NN, src[k]->data(), NN * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)
+      return fail(CSDO_EDEVICE);
+  K0Centres kc{base, base + NN, base + 2 * NN, base + 3 * NN, base + 4 * NN, base + 5 * NN, base + 6 * NN, base + 7 * NN};
+  const double reach = 2 * std::sqrt(2) * parm->r_trust;
+  const float length = (float)veh->LF + (float)veh->LB, width = (float)veh->car_width;
+  if (hipMemsetAsync(h->k0_flag.p, 0, sizeof(int), s) != hipSuccess) return fail(CSDO_EDEVICE);
+  if (k0_count(kc, Na, Nt, reach, length, width, (int*)h->k0_counts.p, (int*)h->k0_flag.p, (long long*)h->k0_offsets.p, s) !=
+      hipSuccess)
+    return fail(CSDO_EDEVICE);
+  long long n_pairs = 0;
+  int collide = 0;
+  if (hipMemcpyAsync(&n_pairs, (long long*)h->k0_offsets.p + NN, sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(&collide, h->k0_flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return fail(CSDO_EDEVICE);
+  if (n_pairs > (long long)0x7fffffff / 3) return fail(CSDO_ELIMIT);
+  std::vector<int32_t> pairs((size_t)3 * n_pairs);
+  std::vector<double> coef((size_t)24 * n_pairs);
+  if (n_pairs > 0) {
+    if ((rc = h->k0_pairs.ensure(pairs.size() * sizeof(int32_t))) != CSDO_OK) return fail(rc);
+    if ((rc = h->k0_coef.ensure(coef.size() * sizeof(double))) != CSDO_OK) return fail(rc);
+    if (k0_emit(kc, Na, Nt, reach, length, width, (double)(float)veh->rv, (const long long*)h->k0_offsets.p,
+                (int32_t*)h->k0_pairs.p, (double*)h->k0_coef.p, s) != hipSuccess)
+      return fail(CSDO_EDEVICE);
+    if (hipMemcpyAsync(pairs.data(), h->k0_pairs.p, pairs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(coef.data(), h->k0_coef.p, coef.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return fail(CSDO_EDEVICE);
+  }
+  if ((rc = bridge_planes(C, pairs, veh, coef.data(), out)) != CSDO_OK) return rc;
+  out->initial_inter_legal = collide ? 0 : 1;
+  return CSDO_OK;
+}
+
+// Independent geometric check of final trajectories on the device: vehicle rectangles against each other per timestep
+// (separating axes, touching counts) and against the obstacle discs, optional map bounds (dimx <= 0: skipped).
+int csdo_validate(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt, const double* obstacles, int32_t n_obs,
+                  double dimx, double dimy, const csdo_vehicle* veh, double margin, csdo_validation* out) {
+  if (!h || !solutions || !veh || !out || Na < 1 || Nt < 1 || n_obs < 0 || (n_obs > 0 && !obstacles)) return CSDO_EINVAL;
+  if (Na >= (1 << 20) || Nt >= (1 << 20) || n_obs >= (1 << 20)) return CSDO_ELIMIT;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  int rc;
+  const size_t b_sol = (size_t)Na * Nt * 6 * sizeof(double), b_obs = (size_t)n_obs * 3 * sizeof(double);
+  if ((rc = h->val_sol.ensure(b_sol)) != CSDO_OK) return rc;
+  if ((rc = h->val_obs.ensure(b_obs)) != CSDO_OK) return rc;
+  if ((rc = h->val_out.ensure(6 * sizeof(unsigned long long))) != CSDO_OK) return rc;
+  hipStream_t s = h->stream;
+  const unsigned long long none = ~0ull;
+  unsigned long long init[6] = {0ull, none, 0ull, none, 0ull, none}, res[6];
+  HIP_OK(hipMemcpyAsync(h->val_sol.p, solutions, b_sol, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  if (n_obs) HIP_OK(hipMemcpyAsync(h->val_obs.p, obstacles, b_obs, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->val_out.p, init, sizeof(init), hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  const double half_shift = 0.5 * (veh->LF - veh->LB), hl = 0.5 * (veh->LF + veh->LB) + margin, hw = 0.5 * veh->car_width + margin;
+  if (validate_launch((const double*)h->val_sol.p, Na, Nt, (const double*)h->val_obs.p, n_obs, half_shift, hl, hw, dimx, dimy,
+                      dimx > 0 && dimy > 0, (unsigned long long*)h->val_out.p, s) != hipSuccess)
+    return CSDO_EDEVICE;
+  HIP_OK(hipMemcpyAsync(res, h->val_out.p, sizeof(res), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
+  out->vehicle_collisions = (int64_t)res[0];
+  out->obstacle_collisions = (int64_t)res[2];
+  out->out_of_map = (int64_t)res[4];
+  for (int k = 0; k < 3; ++k) out->first_vehicle[k] = out->first_obstacle[k] = -1;
+  if (res[0]) {
+    out->first_vehicle[0] = (int32_t)(res[1] >> 40);
+    out->first_vehicle[1] = (int32_t)((res[1] >> 20) & 0xfffff);
+    out->first_vehicle[2] = (int32_t)(res[1] & 0xfffff);
+  }
+  if (res[2]) {
+    out->first_obstacle[0] = (int32_t)(res[3] >> 40);
+    out->first_obstacle[1] = (int32_t)((res[3] >> 20) & 0xfffff);
+    out->first_obstacle[2] = (int32_t)(res[3] & 0xfffff);
+  }
+  out->min_obstacle_clearance = INFINITY;
+  if (n_obs > 0 && res[5] != none) {
+    const unsigned long long key = res[5];
+    const unsigned long long bits = (key & 0x8000000000000000ull) ? (key & 0x7fffffffffffffffull) : ~key;
+    double d;
+    std::memcpy(&d, &bits, sizeof(d));
+    out->min_obstacle_clearance = d;
+  }
+  return CSDO_OK;
+}
 
 void csdo_vehicle_default(csdo_vehicle* v) {
   if (!v) return;

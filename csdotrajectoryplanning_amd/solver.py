@@ -96,6 +96,37 @@ class DsqpHandle:
         p = lib().csdo_dsqp_device_solutions(self._h, C.byref(n))
         return p, int(n.value)
 
+    def interpolate_and_planes(self, states, actions, path_off, goals, veh, parm, dimx, dimy, obstacles):
+        """The bridge with the neighbour search and plane generation on this GPU (csdo_preprocess_device); same return
+        value as the module-level interpolate_and_planes, bit for bit."""
+        bo = abi.BridgeOut()
+        states = np.ascontiguousarray(states, dtype=np.float64)
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        path_off = np.ascontiguousarray(path_off, dtype=np.int32)
+        goals = np.ascontiguousarray(goals, dtype=np.float64)
+        check(lib().csdo_preprocess_device(self._h, abi.as_double_p(states), abi.as_int32_p(actions),
+                                           abi.as_int32_p(path_off), len(path_off) - 1, abi.as_double_p(goals),
+                                           C.byref(veh), C.byref(parm), C.byref(bo)), "csdo_preprocess_device")
+        out = bridge_to_world(bo, dimx, dimy, obstacles, veh, parm)
+        lib().csdo_bridge_free(C.byref(bo))
+        return out
+
+    def validate(self, solutions, veh, obstacles=None, dimx=0.0, dimy=0.0, margin=0.0):
+        """Trajectory validator on this GPU (csdo_validate); returns a results.ValidationReport."""
+        from .results import ValidationReport
+        sol = np.ascontiguousarray(np.asarray(solutions, dtype=np.float64)[..., :6])
+        if sol.shape[-1] < 6:
+            sol = np.ascontiguousarray(np.concatenate([sol, np.zeros(sol.shape[:-1] + (6 - sol.shape[-1],))], -1))
+        obs = np.zeros((0, 3)) if obstacles is None else np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 3)
+        v = abi.Validation()
+        check(lib().csdo_validate(self._h, abi.as_double_p(sol), sol.shape[0], sol.shape[1], abi.as_double_p(obs),
+                                  obs.shape[0], float(dimx or 0.0), float(dimy or 0.0), C.byref(veh), float(margin),
+                                  C.byref(v)), "csdo_validate")
+        fv = tuple(v.first_vehicle) if v.vehicle_collisions else None
+        fo = tuple(v.first_obstacle) if v.obstacle_collisions else None
+        return ValidationReport(int(v.vehicle_collisions), int(v.obstacle_collisions), int(v.out_of_map), fv, fo,
+                                float(v.min_obstacle_clearance))
+
     def generate_boxes(self, points, obstacles, dimx, dimy, veh):
         points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
         obstacles = np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 3)

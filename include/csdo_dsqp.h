@@ -11,6 +11,9 @@
  *                               SolverDSQP construction
  *   csdo_preprocess        <->  InterpolateInitalGuess + findNeighborPairsByTrustRegion + calcEqualInterPlanes
  *                               sqp/inter_agent_cons.h:11-13,40-45,69-73; call sites csdo.cc:116-129
+ *   csdo_preprocess_device <->  the same three calls with the pair search and plane generation on the device
+ *   csdo_validate          <->  collision_rect_and_rect / collision_circle_and_rect over a result
+ *                               scripts/collision_detection.py:20-96 (the authors' post-hoc check, scripts/visualize.py:219-247)
  *   csdo_generate_boxes    <->  generateBox                            sqp/corridor.h:84-88, .cc:124-159
  *   csdo_vehicle_default / csdo_qp_parm_default
  *                          <->  readAgentConfig / readQpSolverConfig   common/motion_planning.cc:54-93,
@@ -168,6 +171,27 @@ typedef struct csdo_bridge_out {
 int csdo_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                     const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
 void csdo_bridge_free(csdo_bridge_out* out);
+/* The same bridge with its two O(Nt Na^2) stages - findNeighborPairsByTrustRegion and calcEqualInterPlanes,
+ * sqp/inter_agent_cons.cc:12-49,54-140 - on the device (one 64-lane workgroup per (t, i), pairs emitted in the reference's
+ * (t, i, j) order); interpolation and CSR assembly stay on the host.  Outputs are bit-identical to csdo_preprocess. */
+int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
+                           const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
+
+/* Independent trajectory validator on the device (the reference checks results the same way after the fact:
+ * scripts/collision_detection.py:20-96 through scripts/visualize.py:40-52,219-247): vehicle rectangles (rear-axle
+ * reference, LF / LB / car_width of `veh`, inflated by `margin`) against each other per timestep - separating axes,
+ * touching counts - and against the obstacle discs; with dimx, dimy > 0 also rectangle corners against the map. */
+typedef struct csdo_validation {
+  int64_t vehicle_collisions;    /* (t, i, j) triples with overlapping rectangles */
+  int64_t obstacle_collisions;   /* (t, agent, obstacle) triples */
+  int64_t out_of_map;            /* (t, agent) pairs with a corner outside the map */
+  int32_t first_vehicle[3];      /* smallest (t, i, j), or -1 */
+  int32_t first_obstacle[3];     /* smallest (t, agent, obstacle), or -1 */
+  double min_obstacle_clearance; /* smallest signed distance rectangle - disc (negative: overlap; +inf without obstacles) */
+} csdo_validation;
+int csdo_validate(csdo_handle h, const double* solutions /* [Na][Nt][6] */, int32_t Na, int32_t Nt,
+                  const double* obstacles /* [n_obs][3] */, int32_t n_obs, double dimx, double dimy,
+                  const csdo_vehicle* veh, double margin, csdo_validation* out);
 
 /* Safe boxes for arbitrary points on the device (one lane per point). boxes: [n][4] x_min,y_min,x_max,y_max;
  * status: [n] bit0 = success, bits 1-2 = initial status (0 legal, 1 out of map, 2 collision). */

@@ -1,0 +1,100 @@
+"""The O(Nt Na^2) kernels either side of the solve (csrc/aux_kernels.hip): neighbour search + separating planes on the
+device against the host bridge (bit for bit), the trajectory validator on the device against the numpy validator and the
+reference's own verdicts (tests/golden/ref_collision_verdicts.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _paths(k, which="map100"):
+    from csdotrajectoryplanning_amd import workloads
+    w, info = (workloads.map100_world(k) if which == "map100" else workloads.map50_world(k))
+    return w, info["paths"]
+
+
+def _same_bridge(a, b):
+    (wa, pa, la), (wb, pb, lb) = a, b
+    assert la == lb and np.array_equal(pa, pb)
+    assert np.array_equal(wa.x0_bar, wb.x0_bar) and np.array_equal(wa.plane_off, wb.plane_off)
+    assert np.array_equal(wa.planes["t"], wb.planes["t"]) and np.array_equal(wa.planes["c"], wb.planes["c"])
+
+
+@pytest.mark.parametrize("which,k", [("map50", 0), ("map100", 0), ("map100", 7)])
+def test_device_bridge_equals_host_bridge(gpu_handle, which, k):
+    from csdotrajectoryplanning_amd.solver import interpolate_and_planes
+    w, (st, ac, po, G) = _paths(k, which)
+    host = interpolate_and_planes(st, ac, po, G, w.veh, w.parm, w.dimx, w.dimy, w.obstacles)
+    dev = gpu_handle.interpolate_and_planes(st, ac, po, G, w.veh, w.parm, w.dimx, w.dimy, w.obstacles)
+    assert len(host[1]) > 0
+    _same_bridge(host, dev)
+
+
+def test_device_bridge_1024_agents_in_one_world(gpu_handle):
+    """The case K0 exists for: 1024 vehicles in ONE world, about 10^8 (t, i, j) candidates.  The coarse paths of
+    21 instances are laid over each other (not a solvable planning instance: a stress input with very many neighbours)."""
+    from csdotrajectoryplanning_amd import synth
+    from csdotrajectoryplanning_amd.solver import interpolate_and_planes
+    S, A, G = [], [], []
+    w0 = None
+    for k in range(21):
+        w, (st, ac, po, g) = _paths(k)
+        w0 = w0 or w
+        for a in range(len(po) - 1):
+            S.append(st[po[a]:po[a + 1]])
+            A.append(ac[po[a] - a:po[a + 1] - a - 1])
+        G.append(g)
+    S, A, G = S[:1024], A[:1024], np.concatenate(G)[:1024]
+    st, ac, po = synth.pack_paths(S, A)
+    host = interpolate_and_planes(st, ac, po, G, w0.veh, w0.parm, w0.dimx, w0.dimy, w0.obstacles)
+    dev = gpu_handle.interpolate_and_planes(st, ac, po, G, w0.veh, w0.parm, w0.dimx, w0.dimy, w0.obstacles)
+    assert host[0].Na == 1024 and len(host[1]) > 100000
+    _same_bridge(host, dev)
+
+
+def test_device_bridge_without_neighbours(gpu_handle, veh_parm):
+    from csdotrajectoryplanning_amd import synth
+    veh, parm = veh_parm
+    step = veh.r * veh.deltat
+    S = [np.array([[8.0 + step * i, 10.0 + 40.0 * a, 0.0] for i in range(5)]) for a in range(2)]
+    A = [np.zeros(4, np.int32) for _ in range(2)]
+    st, ac, po = synth.pack_paths(S, A)
+    G = np.array([s[-1] for s in S])
+    w, pairs, legal = gpu_handle.interpolate_and_planes(st, ac, po, G, veh, parm, 100.0, 100.0, np.zeros((0, 3)))
+    assert len(pairs) == 0 and legal == 1 and int(w.plane_off[-1]) == 0 and w.Nt == 13
+
+
+def test_device_validator_equals_reference_verdicts(gpu_handle, veh_parm):
+    """Every rectangle / rectangle and disc / rectangle verdict of the reference's collision_detection.py."""
+    veh, _ = veh_parm
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_collision_verdicts.npz"))
+    n = len(z["rect_rect"])
+    sol = np.zeros((2, n, 6))
+    sol[0, :, :3], sol[1, :, :3] = z["rect_a"], z["rect_b"]
+    rep = gpu_handle.validate(sol, veh)
+    assert rep.vehicle_collisions == int(z["rect_rect"].sum())
+    assert rep.first_vehicle_collision == (int(np.argmax(z["rect_rect"])), 0, 1)
+    # disc / rectangle: one agent, one timestep and one obstacle per case
+    hits = 0
+    for k in range(0, 600):
+        r = gpu_handle.validate(z["rect_c"][k][None, None, :], veh, z["circle"][k][None, :])
+        assert (r.obstacle_collisions == 1) == bool(z["circle_rect"][k])
+        hits += r.obstacle_collisions
+    assert hits == int(z["circle_rect"][:600].sum())
+
+
+@pytest.mark.parametrize("which,k", [("map50", 3), ("map100", 1)])
+def test_device_validator_equals_numpy_validator_on_results(gpu_handle, which, k):
+    from csdotrajectoryplanning_amd import results
+    w, _ = _paths(k, which)
+    sol = gpu_handle.solve(w).solutions
+    for margin in (0.0, 0.3):
+        ref = results.validate(sol, w.veh, w.obstacles, w.dimx, w.dimy, margin=margin)
+        got = gpu_handle.validate(sol, w.veh, w.obstacles, w.dimx, w.dimy, margin=margin)
+        assert (got.vehicle_collisions, got.obstacle_collisions, got.out_of_map) == \
+               (ref.vehicle_collisions, ref.obstacle_collisions, ref.out_of_map)
+        assert got.first_vehicle_collision == ref.first_vehicle_collision
+        assert got.first_obstacle_collision == ref.first_obstacle_collision
+        assert abs(got.min_obstacle_clearance - ref.min_obstacle_clearance) < 1e-9

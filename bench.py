@@ -63,6 +63,27 @@ def algorithmic_bytes(world, admm_iters):
     return admm_iters.astype("float64") * (2280.0 * world.Nt + 416.0 * K)
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by a cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def _newest_pmc(workload, step_ms):
     """HBM traffic / VALU figures of the dominant kernel from the newest committed PMC summary, or Nones if it does not
     describe this workload at (about) this speed."""
@@ -243,6 +264,12 @@ def main():
             t_b0 = time.perf_counter()
             list(ex.map(_bridge, range(len(worlds))))
             t_bridge = time.perf_counter() - t_b0
+        t_k0 = time.perf_counter()
+        for i in range(len(worlds)):       # the same bridge with the O(Nt Na^2) stages on the device (csdo_preprocess_device)
+            st_, ac_, po_, G_ = infos[i]["paths"]
+            w_ = worlds[i]
+            h.interpolate_and_planes(st_, ac_, po_, G_, w_.veh, w_.parm, w_.dimx, w_.dimy, w_.obstacles)
+        t_bridge_dev = time.perf_counter() - t_k0
         t_u0 = time.perf_counter()
         h.upload(worlds)
         t_upload = time.perf_counter() - t_u0
@@ -252,12 +279,32 @@ def main():
         t_dl = time.perf_counter() - t_d0
         xfer = h.transfer_seconds()
         tot = t_bridge + t_upload + t_k + t_dl
-        e2e = {"bridge_host_ms": t_bridge * 1e3, "bridge_threads": nthr, "upload_h2d_ms": t_upload * 1e3,
+        e2e = {"bridge_host_ms": t_bridge * 1e3, "bridge_threads": nthr, "bridge_device_k0_serial_ms": t_bridge_dev * 1e3, "upload_h2d_ms": t_upload * 1e3,
                "upload_h2d_first_call_ms": t_upload_first * 1e3, "solve_kernels_ms": t_k * 1e3,
                "download_d2h_ms": t_dl * 1e3, "total_ms": tot * 1e3,
                "library_breakdown_ms": {k: v * 1e3 for k, v in xfer.items()},
                "agent_qp_iterations_per_sec": iters_step / tot,
                "note": "PCIe-inclusive DO phase of rank 0's batch; never `value`"}
+
+    # ---- the authors' own acceptance of a result: the trajectory validator (device kernel), per world
+    validation = None
+    if rank == 0:
+        ok_w = ok_obs = 0
+        veh_hits = obs_hits = 0
+        t_v0 = time.perf_counter()
+        for w, s_ in zip(worlds, sols):
+            rep = h.validate(s_.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
+            ok_w += int(rep.ok)
+            ok_obs += int(rep.obstacle_collisions == 0 and rep.out_of_map == 0)
+            veh_hits += rep.vehicle_collisions
+            obs_hits += rep.obstacle_collisions
+        validation = {"worlds": len(worlds), "worlds_without_any_collision": ok_w,
+                      "worlds_without_static_collision": ok_obs, "vehicle_collision_triples": int(veh_hits),
+                      "obstacle_collision_triples": int(obs_hits), "solver_status_ok_worlds":
+                          int(sum(1 for s_ in sols if abs(int(s_.solver_status)) <= 2)),
+                      "validator_ms": (time.perf_counter() - t_v0) * 1e3,
+                      "note": "rectangle/rectangle and disc/rectangle checks of the final trajectories (csdo_validate); "
+                              "inputs are the synthetic front-end stand-in's coarse paths, which are not collision-free"}
 
     per_rank = None
     if dist is not None:
@@ -331,6 +378,7 @@ def main():
             },
             "single_instance": single,
             "do_phase_e2e": e2e,
+            "validation": validation,
             "batch_ms": {"front_end_stand_in_and_bridge_host": t_pre * 1e3, "solve_kernels": kernel_avg * 1e3,
                          "download_d2h": t_download * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -346,7 +394,7 @@ def main():
         }
         if not args.no_cpu_baseline and world_size == 1:
             from tests import oracle_lib
-            cores = os.cpu_count() or 1
+            cores = effective_cpus()
             # bounded sample: the whole batch when the host has the cores for it, else a prefix sized for ~20 s
             est_rate = 1.9e4 * cores                           # measured: 19 k agent-iterations/s per core
             n_s = len(worlds)
@@ -364,6 +412,7 @@ def main():
             oracle_lib.solve(w0, min(cores, w0.Na))
             t_inst = time.perf_counter() - tc0
             out["cpu_baseline"] = {"value": it_cpu / t_all, "unit": "agent-QP-iterations/s", "cores": cores,
+                                   "os_cpu_count": os.cpu_count(),
                                    "kind": "port",
                                    "sample": "the oracle (OSQP-0.6.3-equivalent restatement) over the first %d of the "
                                              "batch's %d worlds = %d agents, ONE thread pool of %d threads over all "

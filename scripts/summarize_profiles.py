@@ -1,7 +1,8 @@
-"""Turns the rocprofv3 output directories of a profiling call (gpurun_out/r01_*) into the committed summaries under
-profiles/: kernel-trace statistics (csv as written by --stats) and the per-dispatch PMC means as JSON.
+"""Turns the rocprofv3 output directories of a profiling call (scripts/profile_round.sh -> gpurun_out/<tag>_<workload>/) into
+the committed summaries under profiles/: kernel-trace statistics (csv as written by --stats) and the PMC means as JSON
+with the derived figures bench.py reports next to the nominal roofline.
 
-usage: python scripts/summarize_profiles.py gpurun_out r01
+usage: python scripts/summarize_profiles.py gpurun_out r02 map100
 """
 import csv
 import glob
@@ -11,54 +12,70 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+wl = sys.argv[3] if len(sys.argv) > 3 else "map100"
+base = os.path.join(src, "%s_%s" % (tag, wl))
 out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(out_dir, exist_ok=True)
+STEPS = 4        # the profiled command runs 1 warm-up + 3 timed steps, one dispatch of the agent kernel per step and class
 
 
 def find(pattern):
-    return sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return sorted(glob.glob(os.path.join(base, pattern), recursive=True))
 
 
-# kernel stats
-for f in find("%s_trace/**/*kernel_stats.csv" % tag):
-    shutil.copy(f, os.path.join(out_dir, "%s_kernel_stats.csv" % tag))
-    print("kernel stats <-", f)
+summary = {"workload": wl}
+for f in find("trace/**/*kernel_stats.csv"):
+    shutil.copy(f, os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, wl)))
     with open(f) as fh:
-        for row in list(csv.DictReader(fh))[:4]:
-            print("   ", {k: row[k] for k in ("Name", "Calls", "AverageNs", "Percentage") if k in row})
-
-summary = {}
-STEPS = 4   # the profiled command runs 1 warm-up + 3 timed steps; a launch group may be two dispatches sharing one queue
-dominant = "dsqp_agent_kernel<512, 0"
+        rows = list(csv.DictReader(fh))
+    for row in rows[:4]:
+        print("   ", {k: row[k] for k in ("Name", "Calls", "AverageNs", "Percentage") if k in row})
+    agent = [r for r in rows if "dsqp_agent_kernel" in r.get("Name", "")]
+    if agent:
+        dom = max(agent, key=lambda r: float(r["TotalDurationNs"]))
+        summary["dominant_kernel"] = dom["Name"]
+        summary["dominant_kernel_avg_ms"] = float(dom["AverageNs"]) * 1e-6
+        summary["ms_per_step"] = sum(float(r["TotalDurationNs"]) for r in agent) * 1e-6 / STEPS if len(agent) == 1 else \
+            float(dom["AverageNs"]) * 1e-6
+pmc = {}
 for sub in ("fetch", "write", "sq"):
-    for f in find("%s_%s/**/*counter_collection.csv" % (tag, sub)):
+    for f in find("%s/**/*counter_collection.csv" % sub):
         per = {}
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("Kernel_Name", "")
                 if "dsqp_agent_kernel" not in name:
                     continue
-                key = (row["Counter_Name"], "dominant" if name.replace("(int)", "").startswith(dominant) or
-                       "<512, 0" in name else "other")
-                per.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)
-                per[key][row["Dispatch_Id"]] += float(row["Counter_Value"])
-        for (cname, which), d in per.items():
+                per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+                per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        for cname, d in per.items():
             vals = list(d.values())
-            summary.setdefault(cname, {})[which] = {"dispatches": len(vals), "mean_per_dispatch": sum(vals) / len(vals),
-                                                    "per_step": sum(vals) / STEPS}
+            pmc[cname] = {"dispatches": len(vals), "per_step": sum(vals) / STEPS}
         print("pmc <-", f)
-if summary:
-    f_kib = summary.get("FETCH_SIZE", {}).get("dominant", {}).get("per_step")
-    w_kib = summary.get("WRITE_SIZE", {}).get("dominant", {}).get("per_step")
-    if f_kib is not None and w_kib is not None:
-        # MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B
-        # per 128-B request, i.e. half the bytes of wide coalesced reads: doubled here (upper bound for this kernel's
-        # 8-B-per-lane accesses, which the guide calls uncalibrated); WRITE_SIZE is taken as is.
-        summary["hbm_bytes_per_launch_dominant_kernel"] = 2.0 * f_kib * 1024.0 + w_kib * 1024.0
-    summary["_note"] = ("rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes), command: "
-                        "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --setup-procs 1 --skip-single-instance; per_step = sum over the "
-                        "dsqp_agent_kernel dispatches / 4 steps (a launch group is a first launch on its share of the CUs plus a "
-                        "second launch on the same queue); 'dominant' = the <512, 0, true> instantiation")
-    with open(os.path.join(out_dir, "%s_pmc_summary.json" % tag), "w") as fh:
-        json.dump(summary, fh, indent=1, sort_keys=True)
-    print(json.dumps(summary, indent=1, sort_keys=True)[:1500])
+summary["pmc_per_step"] = pmc
+g = lambda k: pmc.get(k, {}).get("per_step")
+if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+    # MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per
+    # 128-B request, i.e. half the bytes of wide coalesced reads: doubled here (an upper bound for this kernel's narrower
+    # accesses, which the guide calls uncalibrated); WRITE_SIZE is taken as is.
+    hbm = 2.0 * g("FETCH_SIZE") * 1024.0 + g("WRITE_SIZE") * 1024.0
+    summary["hbm_bytes_per_launch_dominant_kernel"] = hbm
+    if summary.get("ms_per_step"):
+        summary["hbm_counter_GBps"] = hbm / (summary["ms_per_step"] * 1e-3) / 1e9
+        summary["hbm_counter_frac_of_peak"] = summary["hbm_counter_GBps"] / 8000.0
+if g("SQ_WAVE_CYCLES"):
+    wc = g("SQ_WAVE_CYCLES")
+    summary["sq_wait_any_over_wave_cycles"] = g("SQ_WAIT_ANY") / wc if g("SQ_WAIT_ANY") else None
+    summary["sq_active_inst_any_over_wave_cycles"] = g("SQ_ACTIVE_INST_ANY") / wc if g("SQ_ACTIVE_INST_ANY") else None
+    if g("SQ_INSTS_LDS") and g("SQ_LDS_BANK_CONFLICT") is not None:
+        summary["lds_bank_conflict_cycles_per_lds_inst"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_INSTS_LDS")
+    if g("SQ_INSTS_VALU") and summary.get("ms_per_step"):
+        # upper bound of the fp64 issue utilisation: every VALU wave-instruction priced as a 4-cycle fp64 issue slot on one
+        # of the 1024 SIMDs at 2.4 GHz
+        summary["valu_fp64_issue_frac"] = g("SQ_INSTS_VALU") * 4.0 / (1024.0 * 2.4e9 * summary["ms_per_step"] * 1e-3)
+summary["_note"] = ("rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes), command: python3 "
+                    "bench.py --workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --setup-procs 1 --skip-single-instance; "
+                    "per_step = sum over the dsqp_agent_kernel dispatches / 4 steps" % wl)
+with open(os.path.join(out_dir, "%s_%s_pmc_summary.json" % (tag, wl) if wl != "map100" else "%s_pmc_summary.json" % tag), "w") as fh:
+    json.dump(summary, fh, indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in summary.items() if k != "pmc_per_step"}, indent=1, sort_keys=True))

@@ -1319,6 +1319,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           double xt[6], xn[4] = {0, 0, 0, 0};
           CSDO_FOR(k, 6, { xt[k] = SH(vec, k, t); });
           if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
+          // x first: the row loop below also accumulates the lane's share of the NEXT rhs, sigma x + A'(rho z - y) (the same
+          // sums in the same order as publish_rhs), so that every coefficient is touched once per iteration
+          double r6[6], kin[4] = {0, 0, 0, 0};
+          CSDO_FOR(j, 6, {
+            if (j < S.ncols) S.x[j] = alpha * xt[j] + (1.0 - alpha) * S.x[j];
+            r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0;
+          });
           CSDO_FOR(i, NROW, {
             if (S.act & (1u << i)) {
               double zt = 0.0;
@@ -1345,12 +1352,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               if constexpr (keep_dy) WS(C_DY + i, t) = d;
               S.y[i] += d;
               S.z[i] = zn;
+              const double g = fma(rh, zn, -S.y[i]);
+              CSDO_FOR(s_, 3, {
+                if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(S.c[i][s_], g, r6[row_col(i, s_)]);
+              });
+              if constexpr (i < 4) kin[i] = S.cn[i] * g;
             }
           });
-          CSDO_FOR(j, 6, {
-            if (j < S.ncols) S.x[j] = alpha * xt[j] + (1.0 - alpha) * S.x[j];
-          });
-          publish_rhs(S, t);   // own share of the next rhs + the kinematic rows' share for t+1
+          CSDO_FOR(j, 6, { SH(rhs, j, t) = r6[j]; });
+          CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
         }
         CSDO_SYNC();
       };

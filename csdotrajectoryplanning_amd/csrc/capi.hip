@@ -290,13 +290,14 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
     int left = h->n_cu;
     for (size_t g = 0; g < h->groups.size(); ++g) {
       LaunchGroup& G = h->groups[g];
-      const int cap = std::min(G.count, h->n_cu);
+      const int per_cu = dsqp_workgroups_per_cu(G.block, G.lds_bytes);   // 2 for the 256-thread class when its LDS allows
+      const int cap_cu = std::min((G.count + per_cu - 1) / per_cu, h->n_cu);
       int n = (g + 1 == h->groups.size()) ? left : (int)std::lround(h->n_cu * work[g] / std::max(total, 1e-30));
-      n = std::max(1, std::min(n, std::min(cap, std::max(left, 1))));
-      G.primary = n;
+      n = std::max(1, std::min(n, std::min(cap_cu, std::max(left, 1))));
+      G.primary = std::min(n * per_cu, G.count);
       // (the first group is the one whose agents run longest: its share is sized for them and it hands its CUs over as
       // its queue drains; a second launch of it was observed to take CUs ahead of the later groups' first launches)
-      G.elastic = (g == 0 && h->groups.size() > 1) ? 0 : cap - n;
+      G.elastic = (g == 0 && h->groups.size() > 1) ? 0 : std::max(0, std::min(cap_cu * per_cu, G.count) - G.primary);
       left -= n;
     }
   }

@@ -45,7 +45,9 @@ size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) 
 }
 
 constexpr size_t LDS_CAP = 160 * 1024 - 64;   // 160 KB per workgroup minus the kernel's static LDS (queue slot)
+constexpr size_t LDS_CAP_2WG = 80 * 1024 - 64;   // two workgroups of the 256-thread class per CU
 size_t dsqp_lds_capacity() { return LDS_CAP; }
+int dsqp_workgroups_per_cu(int block, size_t lds_bytes) { return (block == 256 && lds_bytes <= LDS_CAP_2WG) ? 2 : 1; }
 
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) {
   // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024
@@ -54,7 +56,7 @@ int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) 
   *rows_lds = 0;
   if (block == 1024) {
     *mode = 3;
-  } else if (dsqp_lds_bytes(nt, n_obs, n_planes, 0, true) <= LDS_CAP) {
+  } else if (dsqp_lds_bytes(nt, n_obs, n_planes, 0, true) <= (block == 256 ? LDS_CAP_2WG : LDS_CAP)) {   // (256: keep two per CU)
     *mode = 0;
     *rows_lds = 1;
   } else {

@@ -80,8 +80,11 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
 // launch order of capi.hip: heaviest first) until it is empty.  Workgroups of a plain grid are dealt round-robin to the
 // 8 XCDs, every XCD refills only its own CUs in order, and a finished CU waited 1.8 ms on average (0.5 ms median) for
 // its next workgroup: 14 % of the CU time of a 3000-agent batch.  Each role runs its own loop (same barriers in both).
+// The 256-thread class (horizons <= 128) is built for two workgroups per CU: a workgroup's waves spend most of a step waiting
+// for LDS round trips and barriers (scripts/microbench2.hip), a second agent on the same SIMDs fills those gaps; its working
+// set (<= 80 KB of LDS, 256 registers per lane) allows it.  The 512-thread class fills the register file by itself.
 template <int BLOCK, int MODE, bool SPLIT>
-__global__ __launch_bounds__(BLOCK) void dsqp_agent_kernel(const DeviceBatch B, const int first, const int count,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kernel(const DeviceBatch B, const int first, const int count,
                                                              int* __restrict__ queue) {
   extern __shared__ __align__(16) double lds[];
   __shared__ int next_in_queue;

@@ -2,9 +2,11 @@
 // (csdo_device_types.h).  Pure C++, no HIP: used by capi.hip for the real launch and by the lane-serial test build.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/csdo_dsqp.h"
@@ -59,11 +61,16 @@ inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   return s;
 }
 
-// returns CSDO_OK or an error code
+// returns CSDO_OK or an error code.  Two passes: sizes and offsets of every world (serial, cheap), then the worlds are
+// filled in parallel by a few host threads (the per-agent plane ordering and the work estimate - a cos / sin per plane -
+// are what takes time: 41 ms single-threaded for the 3000-agent batch).
 inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) {
   if (!worlds || n_worlds < 1) return CSDO_EINVAL;
   hb = HostBatch{};
   hb.prm = make_params(worlds[0].veh, worlds[0].parm);
+  struct Off { size_t agent, x0, plane, tstart, obs; int64_t rows, fac, steps; };
+  std::vector<Off> off(n_worlds + 1);
+  Off cur{0, 0, 0, 0, 0, 0, 0, 0};
   hb.world_first_agent.push_back(0);
   for (int w = 0; w < n_worlds; ++w) {
     const csdo_problem& W = worlds[w];
@@ -81,70 +88,113 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
       const SolverParams pw = make_params(W.veh, W.parm);
       if (std::memcmp(&pw, &hb.prm, sizeof(SolverParams)) != 0) return CSDO_EINVAL;
     }
-    WorldDesc wd{};
-    wd.dimx = W.dimx;
-    wd.dimy = W.dimy;
-    wd.obs_off = (int32_t)(hb.obstacles.size() / 3);
-    wd.n_obs = W.n_obs;
-    hb.obstacles.insert(hb.obstacles.end(), W.obstacles, W.obstacles + (size_t)3 * W.n_obs);
-    hb.worlds.push_back(wd);
+    off[w] = cur;
+    const int64_t K = W.plane_off[W.Na];
+    cur.agent += (size_t)W.Na;
+    cur.x0 += (size_t)W.Na * W.Nt * 6;
+    cur.plane += (size_t)K;
+    cur.tstart += (size_t)W.Na * (W.Nt + 1);
+    cur.obs += (size_t)3 * W.n_obs;
+    cur.rows += 4 * K;
+    cur.fac += (int64_t)W.Na * (FAC_E_DOUBLES + FAC_X_DOUBLES + COLD_DOUBLES) * fac_stride(W.Nt);
+    cur.steps += (int64_t)W.Na * W.Nt;
+    hb.world_first_agent.push_back((int32_t)cur.agent);
     hb.max_obs = std::max(hb.max_obs, (int)W.n_obs);
     hb.max_nt = std::max(hb.max_nt, (int)W.Nt);
-    for (int a = 0; a < W.Na; ++a) {
-      AgentDesc ad{};
-      ad.Nt = W.Nt;
-      ad.world = w;
-      const int k0 = W.plane_off[a], k1 = W.plane_off[a + 1];
-      ad.n_planes = k1 - k0;
-      hb.max_planes = std::max(hb.max_planes, (int)ad.n_planes);
-      ad.x0_off = (int64_t)hb.x0.size();
-      hb.x0.insert(hb.x0.end(), W.x0_bar + (size_t)a * W.Nt * 6, W.x0_bar + (size_t)(a + 1) * W.Nt * 6);
-      ad.plane_off = (int64_t)hb.planes.size();
-      // planes sorted by timestep (stable): a no-op for the reference's pair order, which is t-major
-      std::vector<int> order(ad.n_planes);
-      for (int k = 0; k < ad.n_planes; ++k) order[k] = k0 + k;
-      std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return W.planes[p].t < W.planes[q].t; });
-      ad.tstart_off = (int64_t)hb.tstart.size();
-      std::vector<int32_t> ts(W.Nt + 1, 0);
-      for (int k : order) {
-        const csdo_plane& pl = W.planes[k];
-        if (pl.t < 0 || pl.t >= W.Nt) return CSDO_EINVAL;
-        PlaneDev pd{};
-        pd.t = pl.t;
-        std::memcpy(pd.c, pl.c, sizeof(pd.c));
-        hb.planes.push_back(pd);
-        ts[pl.t + 1]++;
-      }
-      for (int t = 0; t < W.Nt; ++t) ts[t + 1] += ts[t];
-      hb.tstart.insert(hb.tstart.end(), ts.begin(), ts.end());
-      // Work estimate for the launch order.  Agents whose initial guess violates one of its separating planes run
-      // their QPs to the iteration cap for most SQP iterations (measured on the benchmark sets: the plane residual at
-      // x0_bar separates the ~6 % of agents that take 10x longer from the rest almost perfectly); everybody else
-      // converges in 2-3 SQP iterations.  Per-iteration cost grows with the horizon and the plane count.
-      double worst = 0.0;
-      for (int k = k0; k < k1; ++k) {
-        const csdo_plane& pl = W.planes[k];
-        if (pl.t < 0 || pl.t >= W.Nt) return CSDO_EINVAL;
-        const double* xs = W.x0_bar + ((size_t)a * W.Nt + pl.t) * 6;
-        const double cy = std::cos(xs[2]), sy = std::sin(xs[2]);
-        for (int r = 0; r < 4; ++r) {   // rows 0,1: front disc centre, rows 2,3: rear disc (sqp/inter_agent_cons.cc:71-140)
-          const double off = r < 2 ? hb.prm.f2x : hb.prm.r2x;
-          const double res = pl.c[3 * r] * (xs[0] + off * cy) + pl.c[3 * r + 1] * (xs[1] + off * sy) + pl.c[3 * r + 2];
-          worst = std::max(worst, res);
-        }
-      }
-      hb.est_work.push_back((float)((worst > 0.0 ? 10.0 : 1.0) * (2.0 * W.Nt + ad.n_planes)));
-      ad.rows_off = hb.rows_total;
-      hb.rows_total += (int64_t)4 * ad.n_planes;
-      ad.fac_off = hb.fac_total;
-      hb.fac_total += (int64_t)(FAC_E_DOUBLES + FAC_X_DOUBLES + COLD_DOUBLES) * fac_stride(W.Nt);
-      ad.out_off = hb.steps_total;
-      hb.steps_total += W.Nt;
-      hb.agents.push_back(ad);
-    }
-    hb.world_first_agent.push_back((int32_t)hb.agents.size());
   }
-  return CSDO_OK;
+  off[n_worlds] = cur;
+  hb.agents.resize(cur.agent);
+  hb.est_work.resize(cur.agent);
+  hb.worlds.resize(n_worlds);
+  hb.x0.resize(cur.x0);
+  hb.planes.resize(cur.plane);
+  hb.tstart.resize(cur.tstart);
+  hb.obstacles.resize(cur.obs);
+  hb.rows_total = cur.rows;
+  hb.fac_total = cur.fac;
+  hb.steps_total = cur.steps;
+  std::atomic<int> next{0}, err{CSDO_OK}, max_planes{0};
+  auto fill = [&]() {
+    for (;;) {
+      const int w = next.fetch_add(1);
+      if (w >= n_worlds) break;
+      const csdo_problem& W = worlds[w];
+      const Off& o = off[w];
+      WorldDesc wd{};
+      wd.dimx = W.dimx;
+      wd.dimy = W.dimy;
+      wd.obs_off = (int32_t)(o.obs / 3);
+      wd.n_obs = W.n_obs;
+      hb.worlds[w] = wd;
+      if (W.n_obs) std::memcpy(hb.obstacles.data() + o.obs, W.obstacles, sizeof(double) * 3 * (size_t)W.n_obs);
+      std::memcpy(hb.x0.data() + o.x0, W.x0_bar, sizeof(double) * (size_t)W.Na * W.Nt * 6);
+      int64_t rows = o.rows, fac = o.fac, steps = o.steps;
+      std::vector<int> order;
+      std::vector<int32_t> ts((size_t)W.Nt + 1);
+      for (int a = 0; a < W.Na; ++a) {
+        AgentDesc ad{};
+        ad.Nt = W.Nt;
+        ad.world = w;
+        const int k0 = W.plane_off[a], k1 = W.plane_off[a + 1];
+        ad.n_planes = k1 - k0;
+        int mp = max_planes.load();
+        while (ad.n_planes > mp && !max_planes.compare_exchange_weak(mp, ad.n_planes)) {}
+        ad.x0_off = (int64_t)(o.x0 + (size_t)a * W.Nt * 6);
+        ad.plane_off = (int64_t)(o.plane + (size_t)k0);
+        // planes sorted by timestep (stable): a no-op for the reference's pair order, which is t-major
+        order.resize(ad.n_planes);
+        for (int k = 0; k < ad.n_planes; ++k) order[k] = k0 + k;
+        std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return W.planes[p].t < W.planes[q].t; });
+        ad.tstart_off = (int64_t)(o.tstart + (size_t)a * (W.Nt + 1));
+        std::fill(ts.begin(), ts.end(), 0);
+        PlaneDev* dst = hb.planes.data() + ad.plane_off;
+        // Work estimate for the launch order.  Agents whose initial guess violates one of its separating planes run
+        // their QPs to the iteration cap for most SQP iterations (measured on the benchmark sets: the plane residual at
+        // x0_bar separates the ~6 % of agents that take 10x longer from the rest almost perfectly); everybody else
+        // converges in 2-3 SQP iterations.  Per-iteration cost grows with the horizon and the plane count.
+        double worst = 0.0;
+        for (int k = 0; k < ad.n_planes; ++k) {
+          const csdo_plane& pl = W.planes[order[k]];
+          if (pl.t < 0 || pl.t >= W.Nt) {
+            err.store(CSDO_EINVAL);
+            return;
+          }
+          PlaneDev pd{};
+          pd.t = pl.t;
+          std::memcpy(pd.c, pl.c, sizeof(pd.c));
+          dst[k] = pd;
+          ts[pl.t + 1]++;
+          const double* xs = W.x0_bar + ((size_t)a * W.Nt + pl.t) * 6;
+          const double cy = std::cos(xs[2]), sy = std::sin(xs[2]);
+          for (int r = 0; r < 4; ++r) {   // rows 0,1: front disc centre, rows 2,3: rear disc (sqp/inter_agent_cons.cc:71-140)
+            const double offx = r < 2 ? hb.prm.f2x : hb.prm.r2x;
+            const double res = pl.c[3 * r] * (xs[0] + offx * cy) + pl.c[3 * r + 1] * (xs[1] + offx * sy) + pl.c[3 * r + 2];
+            worst = std::max(worst, res);
+          }
+        }
+        for (int t = 0; t < W.Nt; ++t) ts[t + 1] += ts[t];
+        std::memcpy(hb.tstart.data() + ad.tstart_off, ts.data(), sizeof(int32_t) * ts.size());
+        hb.est_work[o.agent + a] = (float)((worst > 0.0 ? 10.0 : 1.0) * (2.0 * W.Nt + ad.n_planes));
+        ad.rows_off = rows;
+        rows += (int64_t)4 * ad.n_planes;
+        ad.fac_off = fac;
+        fac += (int64_t)(FAC_E_DOUBLES + FAC_X_DOUBLES + COLD_DOUBLES) * fac_stride(W.Nt);
+        ad.out_off = steps;
+        steps += W.Nt;
+        hb.agents[o.agent + a] = ad;
+      }
+    }
+  };
+  const int n_thr = std::max(1, std::min({n_worlds, 16, (int)std::thread::hardware_concurrency()}));
+  if (n_thr == 1) {
+    fill();
+  } else {
+    std::vector<std::thread> pool;
+    for (int k = 0; k < n_thr; ++k) pool.emplace_back(fill);
+    for (auto& t : pool) t.join();
+  }
+  hb.max_planes = max_planes.load();
+  return err.load();
 }
 
 // Scatter packed outputs back into per-world csdo_result buffers and aggregate the solver status the way

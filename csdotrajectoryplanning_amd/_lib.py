@@ -63,5 +63,14 @@ def lib():
         L.csdo_vehicle_default.restype = None
         L.csdo_qp_parm_default.argtypes = [C.POINTER(abi.Vehicle), C.POINTER(abi.QpParm)]
         L.csdo_qp_parm_default.restype = None
+        L.csdo_front_end_parm_default.argtypes = [C.POINTER(abi.FrontEndParm)]
+        L.csdo_front_end_parm_default.restype = None
+        L.csdo_front_end_plan.argtypes = [abi.c_double_p, abi.c_double_p, C.c_int32, C.c_double, C.c_double,
+                                          abi.c_double_p, C.c_int32, C.POINTER(abi.Vehicle),
+                                          C.POINTER(abi.FrontEndParm), C.POINTER(abi.Paths)]
+        L.csdo_paths_free.argtypes = [C.POINTER(abi.Paths)]
+        L.csdo_paths_free.restype = None
+        L.csdo_reeds_shepp.argtypes = [C.c_double * 3, C.c_double * 3, C.c_double, C.c_int32 * 5, C.c_double * 5]
+        L.csdo_reeds_shepp.restype = C.c_double
         _LIB = L
     return _LIB

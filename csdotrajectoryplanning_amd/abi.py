@@ -66,6 +66,20 @@ class BridgeOut(C.Structure):
                 ("pairs", c_int32_p)]
 
 
+class FrontEndParm(C.Structure):
+    """csdo_front_end_parm (include/csdo_dsqp.h)."""
+    _fields_ = [("penalty_turning", C.c_double), ("penalty_reversing", C.c_double), ("penalty_cod", C.c_double),
+                ("map_resolution", C.c_double), ("max_closed_set_size", C.c_double), ("time_limit_s", C.c_double),
+                ("node_limit", C.c_int32), ("rand_seed", C.c_uint32)]
+
+
+class Paths(C.Structure):
+    """csdo_paths (include/csdo_dsqp.h)."""
+    _fields_ = [("Na", C.c_int32), ("status", C.c_int32), ("path_off", c_int32_p), ("states", c_double_p),
+                ("actions", c_int32_p), ("seconds", C.c_double), ("hl_expanded", C.c_int32),
+                ("hl_generated", C.c_int32), ("ll_expanded", C.c_int64)]
+
+
 def as_double_p(a):
     return a.ctypes.data_as(c_double_p)
 
@@ -91,4 +105,5 @@ EXPORTED_SYMBOLS = (
     "csdo_dsqp_device_solutions",
     "csdo_preprocess", "csdo_preprocess_device", "csdo_bridge_free", "csdo_validate", "csdo_generate_boxes", "csdo_vehicle_default",
     "csdo_qp_parm_default", "csdo_backend_name",
+    "csdo_front_end_parm_default", "csdo_front_end_plan", "csdo_paths_free", "csdo_reeds_shepp",
 )

@@ -12,6 +12,9 @@
  *   csdo_preprocess        <->  InterpolateInitalGuess + findNeighborPairsByTrustRegion + calcEqualInterPlanes
  *                               sqp/inter_agent_cons.h:11-13,40-45,69-73; call sites csdo.cc:116-129
  *   csdo_preprocess_device <->  the same three calls with the pair search and plane generation on the device
+ *   csdo_front_end_plan    <->  PBS::solve over the spatiotemporal hybrid A* (the "CS" half of CSDO)
+ *                               pbs/PBS.cc:28-66,665-719, hybrid_a_star/hybrid_astar.h:91-207, environment.h:128-521;
+ *                               call site csdo.cc:93-110.  Host code: the search is pointer-chasing, branchy and serial
  *   csdo_validate          <->  collision_rect_and_rect / collision_circle_and_rect over a result
  *                               scripts/collision_detection.py:20-96 (the authors' post-hoc check, scripts/visualize.py:219-247)
  *   csdo_generate_boxes    <->  generateBox                            sqp/corridor.h:84-88, .cc:124-159
@@ -176,6 +179,40 @@ void csdo_bridge_free(csdo_bridge_out* out);
  * (t, i, j) order); interpolation and CSR assembly stay on the host.  Outputs are bit-identical to csdo_preprocess. */
 int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                            const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
+
+/* Front end (host): priority-based search, each agent planned by a spatiotemporal hybrid A* that yields to the agents
+ * ranked above it.  starts / goals [Na][3] = x, y, yaw.  On success (status 1) the paths come back in exactly the layout
+ * csdo_preprocess takes: states [sum L_a][3], actions [sum (L_a - 1)] (0..5 = the six arc primitives of
+ * common/motion_planning.cc:94-109, 6 = wait), path_off [Na+1].  status 0 = no solution within the limits.
+ * Paths satisfy what PBS itself checks; they are not claimed to equal the reference's paths step for step (heap
+ * tie-breaking and OMPL's Reeds-Shepp internals differ). */
+typedef struct csdo_front_end_parm {
+  double penalty_turning, penalty_reversing, penalty_cod;   /* config.yaml: 1.5, 2.0, 2.0 */
+  double map_resolution;                                    /* 2.0 */
+  double max_closed_set_size;                               /* per low-level search; 1e5 (environment.h:455-458) */
+  double time_limit_s;                                      /* csdo.cc:100: 20 */
+  int32_t node_limit;                                       /* high-level nodes; 0 = unlimited */
+  uint32_t rand_seed;                                       /* csdo.cc:93: srand(0) */
+} csdo_front_end_parm;
+typedef struct csdo_paths {
+  int32_t Na, status;
+  int32_t* path_off;
+  double* states;
+  int32_t* actions;
+  double seconds;
+  int32_t hl_expanded, hl_generated;
+  int64_t ll_expanded;
+} csdo_paths;
+void csdo_front_end_parm_default(csdo_front_end_parm* p);
+int csdo_front_end_plan(const double* starts, const double* goals, int32_t Na, double dimx, double dimy,
+                        const double* obstacles /* [n_obs][3] = x, y, r */, int32_t n_obs, const csdo_vehicle* veh,
+                        const csdo_front_end_parm* parm, csdo_paths* out);
+void csdo_paths_free(csdo_paths* p);
+/* Shortest Reeds-Shepp curve between two poses for turning radius rho (the reference takes it from OMPL's
+ * ReedsSheppStateSpace, an external dependency: environment.h:165-200; this library computes it from the 1990 paper's
+ * word families).  types[5]: 0 none, 1 left, 2 straight, 3 right; lengths[5] in units of rho, negative = reverse.
+ * Returns the path length (rho * sum |lengths|). */
+double csdo_reeds_shepp(const double from[3], const double to[3], double rho, int32_t types[5], double lengths[5]);
 
 /* Independent trajectory validator on the device (the reference checks results the same way after the fact:
  * scripts/collision_detection.py:20-96 through scripts/visualize.py:40-52,219-247): vehicle rectangles (rear-axle

@@ -1,0 +1,217 @@
+"""Front end: Reeds-Shepp curves and the priority-based search over spatiotemporal hybrid A*.
+
+Host code inside libcsdo_hip.so: runs without a GPU.  The paths are checked against what the reference's PBS itself
+guarantees (pbs/PBS.cc:130-214 hasConflicts, hybrid_a_star/environment.h:455-521 stateValid): primitive steps, no two vehicle
+rectangles overlapping at equal times (the shorter path parked at its goal), no inflated obstacle touched, goals reached.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from csdotrajectoryplanning_amd import config, front_end, instance, workloads
+from csdotrajectoryplanning_amd._lib import LIB_PATH
+
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB_PATH), reason="libcsdo_hip.so not built")
+
+VEH = config.vehicle_from_config()
+TYPE_TURN = {1: +1.0, 2: 0.0, 3: -1.0}
+
+
+def _integrate(p0, types, lengths, rho):
+    x, y, yaw = p0
+    for ty, ln in zip(types, lengths):
+        if ty == 0:
+            continue
+        k = TYPE_TURN[ty]
+        if k == 0.0:
+            x += rho * ln * math.cos(yaw)
+            y += rho * ln * math.sin(yaw)
+        else:
+            x += rho * k * (math.sin(yaw + k * ln) - math.sin(yaw))
+            y += rho * k * (-math.cos(yaw + k * ln) + math.cos(yaw))
+            yaw += k * ln
+    return x, y, yaw
+
+
+def _wrap(a):
+    return (a + math.pi) % (2 * math.pi) - math.pi
+
+
+def _dubins_lsl(p0, p1, rho):
+    """Forward-only left-straight-left: an independent upper bound on the Reeds-Shepp length."""
+    dx, dy = (p1[0] - p0[0]) / rho, (p1[1] - p0[1]) / rho
+    d, th = math.hypot(dx, dy), math.atan2(dy, dx)
+    a, b = (p0[2] - th) % (2 * math.pi), (p1[2] - th) % (2 * math.pi)
+    psq = 2 + d * d - 2 * math.cos(a - b) + 2 * d * (math.sin(a) - math.sin(b))
+    if psq < 0:
+        return math.inf
+    tmp = math.atan2(math.cos(b) - math.cos(a), d + math.sin(a) - math.sin(b))
+    return rho * (((-a + tmp) % (2 * math.pi)) + math.sqrt(psq) + ((b - tmp) % (2 * math.pi)))
+
+
+def test_reeds_shepp_known_lengths():
+    rs = front_end.reeds_shepp
+    assert rs((0, 0, 0), (4, 0, 0), 1.0)[0] == pytest.approx(4.0, abs=1e-12)
+    assert rs((0, 0, 0), (-2, 0, 0), 1.0)[0] == pytest.approx(2.0, abs=1e-12)          # straight back
+    assert rs((0, 0, 0), (0, 2, math.pi), 1.0)[0] == pytest.approx(math.pi, abs=1e-9)   # half circle to the left
+    assert rs((0, 0, 0), (0, -2, math.pi), 1.0)[0] == pytest.approx(math.pi, abs=1e-9)
+    assert rs((0, 0, 0), (3, 3, math.pi / 2), 3.0)[0] == pytest.approx(3 * math.pi / 2, abs=1e-9)   # quarter circle, rho 3
+    assert rs((1, 2, 0.3), (1, 2, 0.3), 2.0)[0] == pytest.approx(0.0, abs=1e-9)
+    # far apart, both headings along the connecting line: straight
+    assert rs((0, 0, 0.5), (10 * math.cos(0.5), 10 * math.sin(0.5), 0.5), 2.0)[0] == pytest.approx(10.0, abs=1e-9)
+
+
+def test_reeds_shepp_reaches_the_target_and_respects_bounds():
+    rng = np.random.default_rng(11)
+    for _ in range(3000):
+        rho = float(rng.uniform(0.5, 4.0))
+        p0 = (*rng.uniform(-10, 10, 2), float(rng.uniform(-math.pi, math.pi)))
+        p1 = (*rng.uniform(-10, 10, 2), float(rng.uniform(-math.pi, math.pi)))
+        total, ty, ln = front_end.reeds_shepp(p0, p1, rho)
+        x, y, yaw = _integrate(p0, ty, ln, rho)
+        assert abs(x - p1[0]) < 1e-9 and abs(y - p1[1]) < 1e-9 and abs(_wrap(yaw - p1[2])) < 1e-9
+        assert total == pytest.approx(rho * sum(abs(v) for v in ln), rel=1e-12)
+        assert total >= math.hypot(p1[0] - p0[0], p1[1] - p0[1]) - 1e-9
+        assert total >= rho * abs(_wrap(p1[2] - p0[2])) - 1e-9
+        assert total <= _dubins_lsl(p0, p1, rho) + 1e-9           # the forward-only curve is one of the candidates
+        # symmetries of the problem: driving the curve backwards, and mirroring left/right
+        back = front_end.reeds_shepp(p1, p0, rho)[0]
+        mirrored = front_end.reeds_shepp((p0[0], -p0[1], -p0[2]), (p1[0], -p1[1], -p1[2]), rho)[0]
+        assert back == pytest.approx(total, abs=1e-9) and mirrored == pytest.approx(total, abs=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _rect_centre(p):
+    c2r = (VEH.LF + VEH.LB) / 2 - VEH.LB
+    return p[0] + c2r * math.cos(p[2]), p[1] + c2r * math.sin(p[2])
+
+
+def _rects_overlap(p, q, margin=0.0):
+    """Separating-axis test between two vehicle rectangles in double precision; margin shrinks both (negative grows)."""
+    hl, hw = (VEH.LF + VEH.LB) / 2 - margin, VEH.car_width / 2 - margin
+    (ax, ay), (bx, by) = _rect_centre(p), _rect_centre(q)
+    sx, sy = bx - ax, by - ay
+    for th in (p[2], q[2]):
+        for ux, uy in ((math.cos(th), math.sin(th)), (-math.sin(th), math.cos(th))):
+            ra = hl * abs(ux * math.cos(p[2]) + uy * math.sin(p[2])) + hw * abs(-ux * math.sin(p[2]) + uy * math.cos(p[2]))
+            rb = hl * abs(ux * math.cos(q[2]) + uy * math.sin(q[2])) + hw * abs(-ux * math.sin(q[2]) + uy * math.cos(q[2]))
+            if abs(sx * ux + sy * uy) > ra + rb:
+                return False
+    return True
+
+
+def _check_paths(cp, inst, require_goals=True):
+    na = len(inst.starts)
+    step, dyaw = VEH.r * VEH.deltat, VEH.deltat
+    for a in range(na):
+        P, A = cp.path(a), cp.path_actions(a)
+        assert len(P) >= 2 and len(A) == len(P) - 1
+        np.testing.assert_allclose(P[0], inst.starts[a], atol=1e-12)
+        if require_goals:
+            # the final Reeds-Shepp curve is driven in whole primitives plus a linearly scaled fractional one per segment
+            # (environment.h:497-513), so it stops a fraction of a step from the goal; the heading is exact up to float
+            assert math.hypot(*(P[-1, :2] - inst.goals[a][:2])) < 0.5 and abs(_wrap(P[-1, 2] - inst.goals[a][2])) < 1e-3
+        for k, act in enumerate(A):
+            d = math.hypot(*(P[k + 1, :2] - P[k, :2]))
+            turn = abs(_wrap(P[k + 1, 2] - P[k, 2]))
+            assert 0 <= act <= 6
+            if act == 6:
+                assert d == 0 and turn == 0
+            else:
+                assert d <= step + 1e-6 and turn <= dyaw + 1e-6      # a whole primitive or the fractional end of a segment
+                if act in (0, 3):
+                    assert turn < 1e-6
+                # forward primitives move along the heading, reverse ones against it
+                along = (P[k + 1, 0] - P[k, 0]) * math.cos(P[k, 2]) + (P[k + 1, 1] - P[k, 1]) * math.sin(P[k, 2])
+                assert (along >= -1e-9) if act < 3 else (along <= 1e-9)
+        # inflated obstacles in the vehicle frame (State::obsCollision) and the map
+        for p in P[1:]:
+            cs, sn = math.cos(p[2]), math.sin(p[2])
+            for ox, oy, r in inst.obstacles:
+                lx, ly = (ox - p[0]) * cs + (oy - p[1]) * sn, -(ox - p[0]) * sn + (oy - p[1]) * cs
+                assert not (-VEH.LB - 1.2 * r < lx < VEH.LF + 1.2 * r and abs(ly) < VEH.car_width / 2 + 1.2 * r)
+            for off in (VEH.f2x, VEH.r2x):
+                cx, cy = p[0] + off * cs, p[1] + off * sn
+                assert VEH.rv - 1e-5 <= cx <= inst.dimx - VEH.rv + 1e-5 and VEH.rv - 1e-5 <= cy <= inst.dimy - VEH.rv + 1e-5
+    horizon = int(np.diff(cp.path_off).max())
+    for t in range(horizon):
+        poses = [cp.path(a)[min(t, len(cp.path(a)) - 1)] for a in range(na)]
+        for i in range(na):
+            for j in range(i + 1, na):
+                if math.hypot(poses[i][0] - poses[j][0], poses[i][1] - poses[j][1]) < 8.0:
+                    # the search decides in float: allow a hair of overlap at the boundary
+                    assert not _rects_overlap(poses[i], poses[j], margin=1e-4), (t, i, j)
+
+
+def _load(name):
+    return instance.load_instance(os.path.join(workloads.INSTANCE_DIR, name), obs_radius=VEH.obs_radius)
+
+
+def test_open_map_ten_agents():
+    inst = _load("map_100by100_agents10_ex0.yaml")
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH)
+    assert cp is not None and cp.hl_expanded >= 1
+    _check_paths(cp, inst)
+
+
+def test_obstacle_map_fifty_agents_and_determinism():
+    inst = _load("map_100by100_obst50_agents50_ex0.yaml")
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH)
+    assert cp is not None
+    _check_paths(cp, inst)
+    again = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH)
+    np.testing.assert_array_equal(cp.states, again.states)       # srand(seed) inside: same instance, same paths
+    np.testing.assert_array_equal(cp.actions, again.actions)
+    np.testing.assert_array_equal(cp.path_off, again.path_off)
+
+
+def test_head_on_pair():
+    """Two vehicles swapping places along one line: the second one is planned around the first."""
+    starts = np.array([[10.0, 20.0, 0.0], [30.0, 20.0, math.pi]])
+    goals = np.array([[30.0, 20.0, 0.0], [10.0, 20.0, math.pi]])
+
+    class Inst:
+        pass
+    inst = Inst()
+    inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles = starts, goals, 40.0, 40.0, np.zeros((0, 3))
+    cp = front_end.plan(starts, goals, 40.0, 40.0, inst.obstacles, VEH)
+    assert cp is not None
+    _check_paths(cp, inst)
+
+
+def test_crowded_map_needs_priorities():
+    """25 vehicles on the 50 x 50 map: the root has conflicts, the search has to branch on priorities."""
+    inst = _load("map_50by50_obst25_agents25_ex4.yaml")
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH)
+    assert cp is not None and cp.hl_expanded > 1 and cp.hl_generated > cp.hl_expanded
+    _check_paths(cp, inst)
+
+
+def test_limits_and_bad_arguments():
+    inst = _load("map_100by100_obst50_agents50_ex0.yaml")
+    parm = front_end.default_parm()
+    parm.time_limit_s = 1e-4
+    assert front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH, parm) is None
+    # a goal walled in by obstacles: no path, reported as "no solution", not as an error
+    parm = front_end.default_parm()
+    parm.max_closed_set_size = 2000
+    ring = np.array([[20 + 3.0 * math.cos(a), 20 + 3.0 * math.sin(a), 0.8] for a in np.linspace(0, 2 * math.pi, 24)])
+    assert front_end.plan([[5, 5, 0]], [[20, 20, 0]], 40, 40, ring, VEH, parm) is None
+    with pytest.raises(ValueError):
+        front_end.plan(np.zeros((2, 3)), np.zeros((3, 3)), 10, 10, np.zeros((0, 3)), VEH)
+
+
+def test_paths_feed_the_bridge():
+    """Front end -> csdo_preprocess: the initial guess has one fixed horizon and every agent ends at its goal."""
+    from csdotrajectoryplanning_amd.solver import interpolate_and_planes
+    inst = _load("map_100by100_agents10_ex0.yaml")
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH)
+    parm = config.qp_parm_from_config()
+    world, pairs, legal = interpolate_and_planes(cp.states, cp.actions, cp.path_off, inst.goals, VEH, parm, inst.dimx,
+                                                 inst.dimy, inst.obstacles)
+    assert world.Na == 10 and legal
+    x0 = np.asarray(world.x0_bar).reshape(world.Na, world.Nt, 6)
+    np.testing.assert_allclose(x0[:, 0, :2], inst.starts[:, :2], atol=1e-9)
+    np.testing.assert_allclose(x0[:, -1, :2], inst.goals[:, :2], atol=1e-3)

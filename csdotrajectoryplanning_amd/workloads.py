@@ -1,8 +1,10 @@
 """Named workloads: benchmark instance (data fixture) -> front-end stand-in -> bridge -> World.
 
 Instance files under tests/golden/instances/ are data files of the reference's benchmark set (benchmark/map50by50,
-benchmark/map100by100, benchmark/room); BASELINE.json's configs name them.  The coarse paths come from
-synth.rollout_paths (GENERATOR_NAME) because the reference's PBS front end is out of scope.
+benchmark/map100by100, benchmark/room); BASELINE.json's configs name them.  The measured workloads take their coarse
+paths from synth.rollout_paths (GENERATOR_NAME), a deterministic stand-in that never fails, so every instance of a set
+takes part; `front="pbs"` runs the real front end (front_end.plan: priority-based search over hybrid A*) instead and
+raises FrontEndFailed where the search finds nothing, as the reference's does on part of each set.
 """
 import os
 
@@ -17,19 +19,37 @@ MAP50_AGENTS25_SET = "map_50by50_obst25_agents25_ex{}.yaml"
 MAP100_AGENTS50 = "map_100by100_obst50_agents50_ex{}.yaml"
 
 
-def build_world(instance_file, seed=0, veh=None, parm=None, preprocess=None):
-    """Returns (World, info).  `preprocess` defaults to the shipped bridge (csdo_preprocess); tests pass the oracle's."""
+class FrontEndFailed(RuntimeError):
+    """The priority-based search found no set of paths within its limits (search_status 0 of the reference)."""
+
+
+def build_world(instance_file, seed=0, veh=None, parm=None, preprocess=None, front="stand-in", front_parm=None):
+    """Returns (World, info).  `preprocess` defaults to the shipped bridge (csdo_preprocess); tests pass the oracle's.
+    front: "stand-in" (synth.rollout_paths, seeded) or "pbs" (front_end.plan; `seed` is unused)."""
     veh = veh or config.vehicle_from_config()
     parm = parm or config.qp_parm_from_config()
     path = instance_file if os.path.isabs(instance_file) else os.path.join(INSTANCE_DIR, instance_file)
     inst = instance.load_instance(path, obs_radius=veh.obs_radius)
-    S, A, G = synth.rollout_paths(inst, veh, seed)
-    st, ac, po = synth.pack_paths(S, A)
+    search = None
+    if front == "pbs":
+        from . import front_end
+        cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, front_parm)
+        if cp is None:
+            raise FrontEndFailed(os.path.basename(path))
+        st, ac, po, G = cp.states, cp.actions, cp.path_off, inst.goals
+        search = dict(seconds=cp.seconds, hl_expanded=cp.hl_expanded, hl_generated=cp.hl_generated,
+                      ll_expanded=cp.ll_expanded)
+    elif front == "stand-in":
+        S, A, G = synth.rollout_paths(inst, veh, seed)
+        st, ac, po = synth.pack_paths(S, A)
+    else:
+        raise ValueError("front must be 'stand-in' or 'pbs'")
     if preprocess is None:
         world, pairs, legal = interpolate_and_planes(st, ac, po, G, veh, parm, inst.dimx, inst.dimy, inst.obstacles)
     else:
         world, pairs, legal = preprocess(st, ac, po, G, veh, parm, inst)
-    info = dict(instance=os.path.basename(path), generator=synth.GENERATOR_NAME, seed=seed, Na=world.Na, Nt=world.Nt,
+    info = dict(instance=os.path.basename(path), generator="pbs" if search else synth.GENERATOR_NAME, search=search,
+                seed=seed, Na=world.Na, Nt=world.Nt,
                 n_pairs=int(len(pairs)), n_planes=int(world.plane_off[-1]), initial_inter_legal=int(legal),
                 paths=(st, ac, po, G))
     return world, info

@@ -1,0 +1,70 @@
+"""The whole pipeline of csdo.cc:93-159 on this backend: front end (host PBS) -> bridge with its pair search and plane
+generation on the device -> DO phase on the device -> validator on the device, against the oracle fed the same coarse paths.
+
+The worlds here come from the real front end (csdo_front_end_plan), not from the stand-in the measured workloads use, so
+the DO kernels also see the path shapes the reference's own front end produces (Reeds-Shepp endings, waits)."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_sets import FIRST_QP_TOL, _per_agent, _with_max_iter
+
+pytestmark = pytest.mark.gpu
+
+INSTANCES = ["map_100by100_agents10_ex0.yaml", "map_100by100_obst50_agents50_ex0.yaml",
+             "map_100by100_obst50_agents50_ex3.yaml", "map_50by50_obst25_agents25_ex2.yaml",
+             "map_50by50_obst25_agents25_ex4.yaml"]
+_WORLDS = {}
+
+
+def _pipeline_worlds(gpu_handle):
+    if not _WORLDS:
+        import os
+        from csdotrajectoryplanning_amd import config, front_end, instance, workloads
+        veh, parm = config.vehicle_from_config(), config.qp_parm_from_config()
+        for name in INSTANCES:
+            inst = instance.load_instance(os.path.join(workloads.INSTANCE_DIR, name), obs_radius=veh.obs_radius)
+            cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh)
+            assert cp is not None, name
+            world, pairs, legal = gpu_handle.interpolate_and_planes(cp.states, cp.actions, cp.path_off, inst.goals, veh, parm,
+                                                                    inst.dimx, inst.dimy, inst.obstacles)
+            host_world, host_pairs, host_legal = workloads.interpolate_and_planes(
+                cp.states, cp.actions, cp.path_off, inst.goals, veh, parm, inst.dimx, inst.dimy, inst.obstacles)
+            # device bridge == host bridge, bit for bit, on front-end paths as well
+            np.testing.assert_array_equal(np.asarray(world.x0_bar), np.asarray(host_world.x0_bar))
+            np.testing.assert_array_equal(np.asarray(pairs), np.asarray(host_pairs))
+            np.testing.assert_array_equal(np.asarray(world.plane_off), np.asarray(host_world.plane_off))
+            assert bytes(np.asarray(world.planes)) == bytes(np.asarray(host_world.planes)) and legal == host_legal
+            _WORLDS[name] = (world, inst)
+    return _WORLDS
+
+
+def test_first_qp_on_front_end_paths(gpu_handle, oracle):
+    worlds = [_with_max_iter(w, 1) for w, _ in _pipeline_worlds(gpu_handle).values()]
+    got = gpu_handle.solve_batch(worlds)
+    ref = oracle.solve_batch(worlds, 8)
+    d, dc, same = _per_agent(got, ref)
+    assert same.all(), np.nonzero(~same)[0]
+    assert d.max() <= FIRST_QP_TOL and np.median(d) < 1e-8, (float(d.max()), float(np.median(d)))
+
+
+def test_pipeline_end_to_end(gpu_handle, oracle):
+    from csdotrajectoryplanning_amd import results
+    items = list(_pipeline_worlds(gpu_handle).values())
+    worlds = [w for w, _ in items]
+    got = gpu_handle.solve_batch(worlds)
+    ref = oracle.solve_batch(worlds, 8)
+    d, dc, same = _per_agent(got, ref)
+    print("pipeline worlds: identical counts %.3f, <= 1e-6 %.3f, <= 1e-4 %.3f, max %.2e" %
+          (same.mean(), (d <= 1e-6).mean(), (d <= 1e-4).mean(), d.max()))
+    assert same.mean() >= 0.97 and (d <= 1e-4).mean() >= 0.90 and np.median(d) <= 1e-6
+    for (w, inst), g, r in zip(items, got, ref):
+        assert g.solver_status == r.solver_status or {g.solver_status, r.solver_status} <= {1, 2}
+        # the device validator on the device result: what the authors check after the fact (collision_detection.py)
+        v = gpu_handle.validate(g.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
+        vr = results.validate(r.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
+        assert v.obstacle_collisions == vr.obstacle_collisions == 0
+        assert v.vehicle_collisions == vr.vehicle_collisions
+        if g.solver_status == 1:
+            assert v.vehicle_collisions == 0 and v.out_of_map == 0
+        # every vehicle ends where the instance says
+        np.testing.assert_allclose(g.solutions[:, -1, :2], inst.goals[:, :2], atol=0.5)

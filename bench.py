@@ -201,6 +201,37 @@ def main():
             "agent_qp_iterations_per_sec": float(sol0.admm_iters.sum()) / single_kernel,
         }
 
+    # ---- the whole pipeline of csdo.cc:93-159 for that instance: real front end (host PBS over hybrid A*), bridge with its
+    # pair search and planes on the device, DO phase, validator.  Informational: the timed batch below keeps the stand-in
+    # paths, which never fail, so that every instance of the set takes part.
+    pipeline = None
+    if not args.skip_single_instance and rank == 0 and single is not None:
+        from csdotrajectoryplanning_amd import front_end as fe, instance as inst_mod
+        from csdotrajectoryplanning_amd.workloads import INSTANCE_DIR
+        inst0 = inst_mod.load_instance(os.path.join(INSTANCE_DIR, infos[0]["instance"]), obs_radius=w0.veh.obs_radius)
+        cp = fe.plan(inst0.starts, inst0.goals, inst0.dimx, inst0.dimy, inst0.obstacles, w0.veh)
+        if cp is None:
+            pipeline = {"instance": infos[0]["instance"], "search_status": 0}
+        else:
+            t_b0 = time.perf_counter()
+            pw = h.interpolate_and_planes(cp.states, cp.actions, cp.path_off, inst0.goals, w0.veh, w0.parm, inst0.dimx,
+                                          inst0.dimy, inst0.obstacles)[0]
+            t_pb = time.perf_counter() - t_b0
+            t_s0 = time.perf_counter()
+            psol = h.solve(pw)
+            t_ps = time.perf_counter() - t_s0
+            t_v0 = time.perf_counter()
+            prep = h.validate(psol.solutions, pw.veh, pw.obstacles, pw.dimx, pw.dimy)
+            t_pv = time.perf_counter() - t_v0
+            pipeline = {"instance": infos[0]["instance"], "search_status": 1, "Na": pw.Na, "Nt": pw.Nt,
+                        "planes": int(pw.plane_off[-1]), "high_level_nodes": cp.hl_expanded,
+                        "low_level_expansions": cp.ll_expanded,
+                        "ms": {"front_end_host": cp.seconds * 1e3, "bridge_device": t_pb * 1e3,
+                               "do_phase_upload_solve_download": t_ps * 1e3, "validator_device": t_pv * 1e3},
+                        "admm_iterations": int(psol.admm_iters.sum()), "solver_status": int(psol.solver_status),
+                        "vehicle_collision_triples": prep.vehicle_collisions,
+                        "obstacle_collision_triples": prep.obstacle_collisions, "out_of_map": prep.out_of_map}
+
     # ---- the batch ----
     t_u0 = time.perf_counter()
     h.upload(worlds)
@@ -377,6 +408,7 @@ def main():
                 "per_rank": per_rank,
             },
             "single_instance": single,
+            "pipeline_single_instance": pipeline,
             "do_phase_e2e": e2e,
             "validation": validation,
             "batch_ms": {"front_end_stand_in_and_bridge_host": t_pre * 1e3, "solve_kernels": kernel_avg * 1e3,

@@ -13,7 +13,7 @@ N > 1 ranks (torch.distributed.run, one process per GPU, RCCL):
                       agents (csdotrajectoryplanning_amd/sharding.py; agents are independent once their planes are
                       fixed, sqp/dsqp_solver.cc:1198-1220), solves it, and the step ends with the path's only
                       collective, the all-gather of the final trajectories on the device pointer
-          weak        every rank owns a whole, differently seeded copy of the workload
+          weak        every rank owns a whole copy of the workload (its stand-in worlds seeded differently per rank)
 Rank 0 prints ONE JSON line.
 
 metric  = agent-QP-iterations/sec: ADMM iterations executed by all agents of all ranks / wall time of the K steps (max
@@ -156,7 +156,11 @@ def main():
 
     import numpy as np
     from csdotrajectoryplanning_amd.solver import DsqpHandle, interpolate_and_planes
-    from csdotrajectoryplanning_amd.synth import GENERATOR_NAME
+    n_front = sum(1 for i in infos if str(i["generator"]).startswith("front_end"))
+    guesses = ("initial guesses: %d worlds from this repository's front end (PBS over hybrid A*, paths stored by "
+               "tests/golden/make_front_end_paths.py), %d worlds the search does not solve from the seeded stand-in %s"
+               % (n_front, len(infos) - n_front, next((i["generator"] for i in infos
+                                                       if not str(i["generator"]).startswith("front_end")), "-")))
 
     dist = None
     torch.cuda.set_device(local_rank)
@@ -202,8 +206,8 @@ def main():
         }
 
     # ---- the whole pipeline of csdo.cc:93-159 for that instance: real front end (host PBS over hybrid A*), bridge with its
-    # pair search and planes on the device, DO phase, validator.  Informational: the timed batch below keeps the stand-in
-    # paths, which never fail, so that every instance of the set takes part.
+    # pair search and planes on the device, DO phase, validator, with the search run now (the batch below reads the stored
+    # paths of the same search).
     pipeline = None
     if not args.skip_single_instance and rank == 0 and single is not None:
         from csdotrajectoryplanning_amd import front_end as fe, instance as inst_mod
@@ -335,7 +339,7 @@ def main():
                           int(sum(1 for s_ in sols if abs(int(s_.solver_status)) <= 2)),
                       "validator_ms": (time.perf_counter() - t_v0) * 1e3,
                       "note": "rectangle/rectangle and disc/rectangle checks of the final trajectories (csdo_validate); "
-                              "inputs are the synthetic front-end stand-in's coarse paths, which are not collision-free"}
+                              "the stand-in's coarse paths (worlds the search does not solve) are not collision-free"}
 
     per_rank = None
     if dist is not None:
@@ -388,9 +392,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d worlds, %d agents on rank 0 in one batch, Nt %d..%d, %d inter-vehicle planes; "
-                            "benchmark instance files + %s initial guesses"
+                            "benchmark instance files; %s"
                             % (wl_names[args.workload], len(worlds), n_agents, Nts[0], Nts[-1],
-                               int(sum(int(w.plane_off[-1]) for w in worlds)), GENERATOR_NAME),
+                               int(sum(int(w.plane_off[-1]) for w in worlds)), guesses),
                 "workload_key": args.workload,
                 "worlds_total": len(jobs), "agents_total": int(sum(sizes)) * (1 if (strong or world_size == 1) else world_size),
                 "agents_rank0": n_agents,
@@ -411,7 +415,7 @@ def main():
             "pipeline_single_instance": pipeline,
             "do_phase_e2e": e2e,
             "validation": validation,
-            "batch_ms": {"front_end_stand_in_and_bridge_host": t_pre * 1e3, "solve_kernels": kernel_avg * 1e3,
+            "batch_ms": {"load_paths_and_bridge_host": t_pre * 1e3, "solve_kernels": kernel_avg * 1e3,
                          "download_d2h": t_download * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

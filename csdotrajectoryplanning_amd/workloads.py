@@ -1,10 +1,14 @@
 """Named workloads: benchmark instance (data fixture) -> front-end stand-in -> bridge -> World.
 
 Instance files under tests/golden/instances/ are data files of the reference's benchmark set (benchmark/map50by50,
-benchmark/map100by100, benchmark/room); BASELINE.json's configs name them.  The measured workloads take their coarse
-paths from synth.rollout_paths (GENERATOR_NAME), a deterministic stand-in that never fails, so every instance of a set
-takes part; `front="pbs"` runs the real front end (front_end.plan: priority-based search over hybrid A*) instead and
-raises FrontEndFailed where the search finds nothing, as the reference's does on part of each set.
+benchmark/map100by100, benchmark/room); BASELINE.json's configs name them.  Coarse paths (SURVEY 8d "Initial guesses"):
+  front="auto"      the named workloads' default: the paths this repository's own front end (front_end.plan, PBS over hybrid
+                    A*) produced for the instance, stored under tests/golden/front_end_paths/ by make_front_end_paths.py;
+                    the instances that search does not solve (unsolved.json: 2 of map100's 60, 12 of map50's 60) fall back
+                    to the stand-in so that every instance of a set takes part
+  front="pbs"       run the search now; raises FrontEndFailed where it finds nothing
+  front="stand-in"  synth.rollout_paths (GENERATOR_NAME): seeded primitive roll-outs, never fails, not collision-free;
+                    the committed golden fixtures and the small test worlds are built from it
 """
 import os
 
@@ -23,32 +27,54 @@ class FrontEndFailed(RuntimeError):
     """The priority-based search found no set of paths within its limits (search_status 0 of the reference)."""
 
 
+PATHS_DIR = os.path.join(_ROOT, "tests", "golden", "front_end_paths")
+
+
+def stored_paths(instance_name):
+    """(states, actions, path_off) the front end produced for a benchmark instance, or None (not solved / not stored)."""
+    f = os.path.join(PATHS_DIR, os.path.basename(instance_name).replace(".yaml", ".npz"))
+    if not os.path.exists(f):
+        return None
+    import numpy as np
+    with np.load(f) as z:
+        return z["states"], z["actions"], z["path_off"]
+
+
 def build_world(instance_file, seed=0, veh=None, parm=None, preprocess=None, front="stand-in", front_parm=None):
     """Returns (World, info).  `preprocess` defaults to the shipped bridge (csdo_preprocess); tests pass the oracle's.
-    front: "stand-in" (synth.rollout_paths, seeded) or "pbs" (front_end.plan; `seed` is unused)."""
+    front: see the module docstring; `seed` only matters where the stand-in is used."""
     veh = veh or config.vehicle_from_config()
     parm = parm or config.qp_parm_from_config()
     path = instance_file if os.path.isabs(instance_file) else os.path.join(INSTANCE_DIR, instance_file)
     inst = instance.load_instance(path, obs_radius=veh.obs_radius)
     search = None
-    if front == "pbs":
+    if front == "auto":
+        stored = stored_paths(path)
+        front = "stored" if stored is not None else "stand-in"
+    if front == "stored":
+        st, ac, po = stored
+        G = inst.goals
+        generator = "front_end.plan (stored)"
+    elif front == "pbs":
         from . import front_end
         cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, front_parm)
         if cp is None:
             raise FrontEndFailed(os.path.basename(path))
         st, ac, po, G = cp.states, cp.actions, cp.path_off, inst.goals
+        generator = "front_end.plan"
         search = dict(seconds=cp.seconds, hl_expanded=cp.hl_expanded, hl_generated=cp.hl_generated,
                       ll_expanded=cp.ll_expanded)
     elif front == "stand-in":
         S, A, G = synth.rollout_paths(inst, veh, seed)
         st, ac, po = synth.pack_paths(S, A)
+        generator = synth.GENERATOR_NAME
     else:
-        raise ValueError("front must be 'stand-in' or 'pbs'")
+        raise ValueError("front must be 'auto', 'stand-in' or 'pbs'")
     if preprocess is None:
         world, pairs, legal = interpolate_and_planes(st, ac, po, G, veh, parm, inst.dimx, inst.dimy, inst.obstacles)
     else:
         world, pairs, legal = preprocess(st, ac, po, G, veh, parm, inst)
-    info = dict(instance=os.path.basename(path), generator="pbs" if search else synth.GENERATOR_NAME, search=search,
+    info = dict(instance=os.path.basename(path), generator=generator, search=search,
                 seed=seed, Na=world.Na, Nt=world.Nt,
                 n_pairs=int(len(pairs)), n_planes=int(world.plane_off[-1]), initial_inter_legal=int(legal),
                 paths=(st, ac, po, G))
@@ -58,18 +84,18 @@ def build_world(instance_file, seed=0, veh=None, parm=None, preprocess=None, fro
 MAP100_SET_SIZE = 60   # benchmark/map100by100/agents50/obstacle holds ex0 .. ex59
 
 
-def map100_world(k, veh=None, parm=None, seed_offset=0):
-    """Instance ex{k} of the map100by100/agents50/obstacle set; the front-end stand-in is seeded with k + seed_offset."""
-    return build_world(MAP100_AGENTS50.format(k), seed=k + seed_offset, veh=veh, parm=parm)
+def map100_world(k, veh=None, parm=None, seed_offset=0, front="auto"):
+    """Instance ex{k} of the map100by100/agents50/obstacle set; where the stand-in is used it is seeded with k + seed_offset."""
+    return build_world(MAP100_AGENTS50.format(k), seed=k + seed_offset, veh=veh, parm=parm, front=front)
 
 
 MAP50_SET_SIZE = 60    # benchmark/map50by50/agents25/obstacle holds ex0 .. ex59
 
 
-def map50_world(k, veh=None, parm=None, seed_offset=0):
+def map50_world(k, veh=None, parm=None, seed_offset=0, front="auto"):
     """Instance ex{k} of the map50by50/agents25/obstacle set (BASELINE.json configs[1]); seed k + seed_offset.
     (ex0 with seed 0 is the world the single-instance fixtures and tests use.)"""
-    return build_world(MAP50_AGENTS25_SET.format(k), seed=k + seed_offset, veh=veh, parm=parm)
+    return build_world(MAP50_AGENTS25_SET.format(k), seed=k + seed_offset, veh=veh, parm=parm, front=front)
 
 
 SYNTH1024_AGENTS = 1024

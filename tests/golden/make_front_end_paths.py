@@ -1,0 +1,51 @@
+"""Coarse paths of this repository's own front end (csdo_front_end_plan) for the benchmark instances under
+tests/golden/instances: the initial guesses of the measured workloads (SURVEY 8d "Initial guesses": the build's own host
+front end once it exists).  One .npz per instance that the search solves; instances it does not solve are listed in
+unsolved.json and keep the seeded stand-in generator (synth.py).
+
+The search is deterministic for given limits (srand(seed) inside, no wall-clock decisions below the time limit); the time
+limit here is generous so that it never decides.  tests/test_front_end.py re-plans some instances and compares.
+
+usage: python tests/golden/make_front_end_paths.py [procs]
+"""
+import json
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from csdotrajectoryplanning_amd import config, front_end, instance, workloads  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "front_end_paths")
+TIME_LIMIT_S = 120.0
+
+
+def run(name):
+    veh = config.vehicle_from_config()
+    inst = instance.load_instance(os.path.join(workloads.INSTANCE_DIR, name), obs_radius=veh.obs_radius)
+    parm = front_end.default_parm()
+    parm.time_limit_s = TIME_LIMIT_S
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, parm)
+    if cp is None:
+        return name, None
+    np.savez_compressed(os.path.join(OUT, name.replace(".yaml", ".npz")), states=cp.states, actions=cp.actions,
+                        path_off=cp.path_off, hl_expanded=cp.hl_expanded, ll_expanded=cp.ll_expanded)
+    return name, (cp.seconds, cp.hl_expanded, cp.ll_expanded)
+
+
+if __name__ == "__main__":
+    procs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    names = sorted(n for n in os.listdir(workloads.INSTANCE_DIR) if n.endswith(".yaml"))
+    os.makedirs(OUT, exist_ok=True)
+    with ProcessPoolExecutor(procs) as ex:
+        res = list(ex.map(run, names))
+    unsolved = sorted(n for n, r in res if r is None)
+    with open(os.path.join(OUT, "unsolved.json"), "w") as f:
+        json.dump({"time_limit_s": TIME_LIMIT_S, "unsolved": unsolved}, f, indent=1)
+    ok = [r for _, r in res if r is not None]
+    print("solved %d of %d; search seconds mean %.2f max %.2f" % (len(ok), len(res), np.mean([r[0] for r in ok]),
+                                                                   max(r[0] for r in ok)))
+    print("unsolved:", unsolved)

@@ -189,6 +189,24 @@ def test_crowded_map_needs_priorities():
     _check_paths(cp, inst)
 
 
+def test_stored_paths_are_what_the_search_returns():
+    """tests/golden/front_end_paths/*.npz (the measured workloads' initial guesses) against a fresh search."""
+    import json
+    for name in ("map_100by100_obst50_agents50_ex3.yaml", "map_50by50_obst25_agents25_ex2.yaml"):
+        inst = _load(name)
+        cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH)
+        st, ac, po = workloads.stored_paths(name)
+        np.testing.assert_array_equal(cp.states, st)
+        np.testing.assert_array_equal(cp.actions, ac)
+        np.testing.assert_array_equal(cp.path_off, po)
+    with open(os.path.join(workloads.PATHS_DIR, "unsolved.json")) as f:
+        unsolved = json.load(f)["unsolved"]
+    assert all(workloads.stored_paths(n) is None for n in unsolved)
+    solved100 = sum(workloads.stored_paths(workloads.MAP100_AGENTS50.format(k)) is not None for k in range(60))
+    solved50 = sum(workloads.stored_paths(workloads.MAP50_AGENTS25_SET.format(k)) is not None for k in range(60))
+    assert (solved100, solved50) == (58, 48)
+
+
 def test_limits_and_bad_arguments():
     inst = _load("map_100by100_obst50_agents50_ex0.yaml")
     parm = front_end.default_parm()

@@ -100,8 +100,8 @@ struct csdo_handle_s {
   } while (0)
 
 
-// Groups the agents of the uploaded batch by kernel class and orders each group heaviest-first by the work estimate
-// of batch_pack.h (workgroups are dispatched in index order, so the agents expected to run longest start first:
+// Groups the agents of the uploaded batch by kernel class and orders each group by batch_pack.h's launch rank, likely
+// long runners first (workgroups are dispatched in index order, so the agents expected to run longest start first:
 // longest-processing-time scheduling over the 256 CUs).
 static int build_groups(csdo_handle h) {
   const HostBatch& hb = h->hb;
@@ -130,6 +130,7 @@ static int build_groups(csdo_handle h) {
     // that their longest agents start at once and the faster classes fill the CUs they release
     if (key[p].mode != key[q].mode) return key[p].mode > key[q].mode;
     if (key[p].block != key[q].block) return key[p].block > key[q].block;
+    if (hb.launch_rank[p] != hb.launch_rank[q]) return hb.launch_rank[p] > hb.launch_rank[q];
     return hb.est_work[p] > hb.est_work[q];
   });
   h->groups.clear();

@@ -52,7 +52,10 @@ int dsqp_workgroups_per_cu(int block, size_t lds_bytes) { return (block == 256 &
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) {
   // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024
   // threads with 128 registers per lane: correct but spills; horizons that long are outside the benchmark sets)
-  const int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : 1024);
+  // The 256-thread class runs two workgroups per CU, so it only takes agents whose working set fits half the LDS; a
+  // short horizon that does not (Nt > ~105 with 25 obstacles) runs in the 512-thread class with half its lanes idle.
+  int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : 1024);
+  if (block == 256 && dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) > LDS_CAP_2WG) block = 512;
   *rows_lds = 0;
   if (block == 1024) {
     *mode = 3;

@@ -36,8 +36,10 @@ def main():
     built = workloads.build_jobs_parallel(workloads.workload_jobs(wl), 16)
     worlds = [w for w, _ in built]
     h = DsqpHandle(0)
-    h.solve_batch(worlds)
-    sols = h.solve_batch(worlds)
+    h.upload(worlds)
+    h.run()
+    h.run()
+    sols = h.download()
     secs = np.concatenate([s.agent_seconds for s in sols])
     np.savez(out, seconds=secs, Nt=np.concatenate([np.full(w.Na, w.Nt) for w in worlds]),
              K=np.concatenate([np.diff(np.asarray(w.plane_off)) for w in worlds]),

@@ -298,7 +298,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
       G.primary = std::min(n * per_cu, G.count);
       // (the first group is the one whose agents run longest: its share is sized for them and it hands its CUs over as
       // its queue drains; a second launch of it was observed to take CUs ahead of the later groups' first launches)
-      G.elastic = (g == 0 && h->groups.size() > 1) ? 0 : std::max(0, std::min(cap_cu * per_cu, G.count) - G.primary);
+      G.elastic = std::max(0, std::min(cap_cu * per_cu, G.count) - G.primary);
       left -= n;
     }
   }
@@ -366,7 +366,9 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
     RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].primary, gs));
     RUN_OK(hipEventRecord(h->g_end[g], gs));
   }
-  for (int g = 0; g < ng; ++g) {   // second launches: same queues, workgroups that start on CUs other groups release
+  // second launches: same queues, workgroups that start on CUs other groups release; the first group's comes last so
+  // that it does not take CUs ahead of the later groups' first launches
+  for (int g = ng - 1; g >= 0; --g) {
     if (h->groups[g].elastic <= 0) continue;
     RUN_OK(hipStreamWaitEvent(h->side2[g], h->g_zeroed[g], 0));
     RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, h->side2[g]));

@@ -1,0 +1,24 @@
+"""Safe boxes of the device program (lane-serial host build of the same source) against the oracle's independent restatement
+of sqp/corridor.cc:124-324, bit for bit, on random maps: open space, sparse and dense obstacle fields (more obstacles near
+a point than the program keeps in registers), points outside the map and points hugging inflated obstacles."""
+import numpy as np
+
+
+def test_boxes_bit_identical_on_random_maps(veh_parm, oracle, emu):
+    veh, _ = veh_parm
+    rng = np.random.default_rng(5)
+    for trial in range(14):
+        dim = float(rng.choice([30, 50, 100]))
+        n_obs = int([0, 3, 10, 25, 50, 120, 300][trial % 7])
+        obs = (np.column_stack([rng.uniform(0, dim, n_obs), rng.uniform(0, dim, n_obs), rng.choice([0.5, 0.8, 1.5], n_obs)])
+               if n_obs else np.zeros((0, 3)))
+        pts = rng.uniform(-2, dim + 2, (1500, 2))
+        if n_obs:
+            k = rng.integers(0, n_obs, 500)
+            ang = rng.uniform(0, 2 * np.pi, 500)
+            d = obs[k, 2] + veh.rv + rng.normal(0, 0.05, 500)
+            pts = np.vstack([pts, np.column_stack([obs[k, 0] + d * np.cos(ang), obs[k, 1] + d * np.sin(ang)])])
+        bo, so = oracle.generate_boxes(pts, obs, dim, dim, veh)
+        be, se = emu.generate_boxes(pts, obs, dim, dim, veh)
+        np.testing.assert_array_equal(so, se)
+        np.testing.assert_array_equal(bo, be)

@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=("map100", "map50", "synth1024"), default="map100")
+    ap.add_argument("--front", choices=("auto", "stand-in"), default="auto",
+                    help="initial guesses: the front end's stored paths where it solves the instance (auto, default) or the "
+                         "seeded stand-in for every instance (the round-1 workload, for like-for-like comparisons)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: shard the batch's agents over the ranks (strong) or one whole copy per rank (weak)")
     ap.add_argument("--instances", type=int, default=None, help="instances of the set (default: the whole set)")
@@ -135,7 +138,8 @@ def main():
     from multiprocessing import get_context
     from csdotrajectoryplanning_amd import sharding, workloads
     t_pre0 = time.perf_counter()
-    jobs = workloads.workload_jobs(args.workload, args.instances, seed_offset=0 if (strong or world_size == 1) else 60 * rank)
+    jobs = workloads.workload_jobs(args.workload, args.instances, seed_offset=0 if (strong or world_size == 1) else 60 * rank,
+                                   front=args.front)
     sizes = [workloads.job_agents(j) for j in jobs]
     if strong:   # this rank only builds the worlds its block of agents overlaps
         plan = sharding.shard_batch_plan(sizes, rank, world_size)

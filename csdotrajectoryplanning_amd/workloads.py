@@ -123,25 +123,25 @@ def synthetic_1024(veh=None, parm=None, seed_offset=0, n_agents=SYNTH1024_AGENTS
 WORKLOADS = ("map100", "map50", "synth1024")
 
 
-def workload_jobs(name, n_instances=None, seed_offset=0):
-    """(builder, k, seed_offset) jobs of a named bench workload, one per world, for a process pool."""
+def workload_jobs(name, n_instances=None, seed_offset=0, front="auto"):
+    """(builder, k, seed_offset, front) jobs of a named bench workload, one per world, for a process pool."""
     if name == "map100":
         n = MAP100_SET_SIZE if n_instances is None else max(1, min(int(n_instances), MAP100_SET_SIZE))
-        return [("map100", k, seed_offset) for k in range(n)]
+        return [("map100", k, seed_offset, front) for k in range(n)]
     if name == "map50":
         n = MAP50_SET_SIZE if n_instances is None else max(1, min(int(n_instances), MAP50_SET_SIZE))
-        return [("map50", k, seed_offset) for k in range(n)]
+        return [("map50", k, seed_offset, front) for k in range(n)]
     if name == "synth1024":
-        return [("synth1024", k, seed_offset) for k in range(21)]
+        return [("synth1024", k, seed_offset, front) for k in range(21)]
     raise ValueError("unknown workload %r (one of %s)" % (name, ", ".join(WORKLOADS)))
 
 
 def build_job(job):
     """Build one world of a workload (see workload_jobs); returns (World, info)."""
-    kind, k, seed_offset = job
+    kind, k, seed_offset, front = job
     if kind == "map50":
-        return map50_world(k, seed_offset=seed_offset)
-    w, info = map100_world(k, seed_offset=seed_offset)
+        return map50_world(k, seed_offset=seed_offset, front=front)
+    w, info = map100_world(k, seed_offset=seed_offset, front=front)
     if kind == "synth1024" and k == 20:
         left = SYNTH1024_AGENTS - 20 * 50
         w = w.subset(0, left)
@@ -151,7 +151,7 @@ def build_job(job):
 
 def job_agents(job):
     """Number of agents of a workload job's world, known without building it (sharding plans need it up front)."""
-    kind, k, _ = job
+    kind, k = job[0], job[1]
     if kind == "map50":
         return 25
     if kind == "synth1024" and k == 20:

@@ -431,121 +431,164 @@ CSDO_FN bool box_valid(const BoxD& b, const double* obs, int n_obs, double dimx,
   return !hit;
 }
 
-// The culled obstacles of one seed point held in registers (first OBS_NEAR of them - 6 measured best of 4 / 6 / 8 on the
-// benchmark maps, where 3.4 obstacles survive the cull on average -; any further ones stay in the
-// mask).  Unused slots hold an obstacle at x = +inf, which fails `ox < x_max + infl` for every box.
-constexpr int OBS_NEAR = 6;
-struct ObsNear {
-  double ox[OBS_NEAR], oy[OBS_NEAR], infl[OBS_NEAR];
-  ObsMask rest;
-  bool has_rest;
-};
+// generateLocalBox, corridor.cc:278-324: grow by 0.1 in the order +y, -x, -y, +x until blocked or >= 10 m.
+// isBoxValid's obstacle test is the conjunction of four strict inequalities, one per box side.
+//
+// The reference walks 404 trials; done trial by trial on the device that is ~60 VALU instructions per trial whatever the
+// surroundings, it saturates the SIMDs (both roles grow boxes at the same time) and was 15-20 % of a short agent's time.
+// But the process has very little freedom.  While a side is moving it takes exactly one step per round, so for every
+// (obstacle, side) there is a first step count E at which that side's inequality turns true - and it stays true - and a
+// trial of side d in round r fails exactly when some obstacle has all four inequalities true with the sides before d in the
+// round at r steps and the sides after d at r-1.  For one obstacle that first happens in round max_e E_e, at the LAST side
+// (in round order) that attains the maximum; a side that stops earlier with its inequality still false removes the obstacle
+// for good.  So the whole growth is four "a side stops" events (blocked by an obstacle, by the map border, or after the
+// 101 steps that make len >= 10 in floating point), each found by a minimum over the culled obstacles, followed by a replay
+// of the accepted steps so that every coordinate is the same sequence of floating-point additions as in the reference.
+// E comes from a quotient; the sequential sums differ from c0 + n * 0.1 by < 1e-12, so the quotient is only trusted when it is
+// further than 1e-7 steps from an integer; otherwise E is found by replaying the additions against the exact inequality.
+// Results are bit-identical to the trial-by-trial walk (tests/test_boxes_serial.py against the oracle's, random maps).
+#if defined(CSDO_GROW_STATS)
+inline long csdo_grow_stats[2] = {0, 0};
+#endif
+constexpr int grow_limit_steps() {   // accepted steps until len >= l_limit, len summed as the reference does: 101
+  double len = 0.0;
+  int n = 0;
+  while (!(len >= 10.0)) {
+    len += 0.1;
+    ++n;
+  }
+  return n;
+}
+constexpr int GROW_LIMIT = grow_limit_steps();
+constexpr int GROW_NEVER = 120;      // "not within any reachable step count"
 
-CSDO_FN ObsNear load_near(const ObsMask& M, const double* obs, int n_obs, double rv) {
-  ObsNear R;
-  ObsMask m = M;
-  CSDO_FOR(j, OBS_NEAR, {
-    int k = -1;
-    if (m.m[0]) {
-      k = ctz64(m.m[0]);
-      m.m[0] &= m.m[0] - 1;
-    } else if (m.m[1]) {
-      k = 64 + ctz64(m.m[1]);
-      m.m[1] &= m.m[1] - 1;
-    } else if (m.m[2]) {
-      k = 128 + ctz64(m.m[2]);
-      m.m[2] &= m.m[2] - 1;
-    } else if (m.m[3]) {
-      k = 192 + ctz64(m.m[3]);
-      m.m[3] &= m.m[3] - 1;
+// Step count at which a side's inequality against a threshold turns true.  Side d (0: +y, 1: -x, 2: -y, 3: +x) moves the
+// coordinate c_n (c_0 = c0, c_n = c_{n-1} +- 0.1, summed sequentially); the inequality is  o < c_n + infl  for the sides that
+// move up and  c_n - infl < o  for the sides that move down (isBoxValid's forms; the map border is the same with infl = 0).
+// Returns the smallest n >= 0 for which it holds (it is monotone in n), GROW_NEVER if none is in reach.
+CSDO_FN int first_step(const int d, const double xc, const double yc, const double ox, const double oy, const double infl) {
+  const bool vertical = (d & 1) == 0, up = (d == 0 || d == 3);
+  const double c0 = vertical ? yc : xc, o = vertical ? oy : ox;
+  const double step = up ? 0.1 : -0.1;
+  const double g = (up ? ((o - infl) - c0) : (c0 - (o + infl))) * 10.0;
+  if (!(g > -1.0)) return 0;                      // beyond by more than a step already
+  if (!(g < (double)GROW_NEVER)) return GROW_NEVER;
+  const double fl = floor(g);
+  const double frac = g - fl;
+  if (frac < 1e-7 || frac > 1.0 - 1e-7) {         // too close to call from the quotient: walk the additions
+#if defined(CSDO_GROW_STATS)
+    csdo_grow_stats[1]++;
+#endif
+    double c = c0;
+    int n = 0;
+    while (n < GROW_NEVER && !(up ? (o < (c + infl)) : ((c - infl) < o))) {
+      c += step;
+      ++n;
     }
-    R.ox[j] = (k >= 0) ? obs[k] : INFINITY;
-    R.oy[j] = (k >= 0) ? obs[n_obs + k] : 0.0;
-    R.infl[j] = (k >= 0) ? (obs[2 * n_obs + k] + rv) : 0.0;
-  });
-  R.rest = m;
-  R.has_rest = (m.m[0] | m.m[1] | m.m[2] | m.m[3]) != 0ull || n_obs > OBS_MASK_CAP;
-  return R;
+    return n;
+  }
+  return (g < 0.0) ? 0 : (int)fl + 1;
 }
 
-// generateLocalBox, corridor.cc:278-324: grow by 0.1 in the order +y, -x, -y, +x until blocked or >= 10 m.
-// isBoxValid's obstacle test is the conjunction of four strict inequalities, one per box side; a trial step moves one
-// side, so only that side's inequality is re-evaluated (one bit per register-held obstacle) and and-ed with the
-// cached bits of the other three sides: same booleans as testing the whole trial box against every obstacle.
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
                       BoxD& res) {
-  const double ds = 0.1, l_limit = 10.0;
+  const double ds = 0.1;
   const ObsMask M = cull_obstacles(xc, yc, obs, n_obs, rv);
-  const ObsNear R = load_near(M, obs, n_obs, rv);
-  BoxD box{xc, yc, xc, yc};
-  // side bits of the current box: bit j set <=> obstacle j satisfies that side's inequality
-  unsigned s_ymax = 0, s_xmin = 0, s_ymin = 0, s_xmax = 0;
-  CSDO_FOR(j, OBS_NEAR, {
-    s_ymax |= (R.oy[j] < (box.y_max + R.infl[j])) ? (1u << j) : 0u;
-    s_xmin |= ((box.x_min - R.infl[j]) < R.ox[j]) ? (1u << j) : 0u;
-    s_ymin |= ((box.y_min - R.infl[j]) < R.oy[j]) ? (1u << j) : 0u;
-    s_xmax |= (R.ox[j] < (box.x_max + R.infl[j])) ? (1u << j) : 0u;
-  });
-  double len[4] = {0, 0, 0, 0};
-  bool on[4] = {true, true, true, true};
-  int num_expand = 0;
-  while (on[0] || on[1] || on[2] || on[3]) {
-    CSDO_FOR(d, 4, {
-      if (on[d]) {
-        BoxD tr = box;
-        unsigned t_ymax = s_ymax, t_xmin = s_xmin, t_ymin = s_ymin, t_xmax = s_xmax;
-        if constexpr (d == 0) {
-          tr.y_max += ds;
-          t_ymax = 0;
-          CSDO_FOR(j, OBS_NEAR, { t_ymax |= (R.oy[j] < (tr.y_max + R.infl[j])) ? (1u << j) : 0u; });
-        }
-        if constexpr (d == 1) {
-          tr.x_min -= ds;
-          t_xmin = 0;
-          CSDO_FOR(j, OBS_NEAR, { t_xmin |= ((tr.x_min - R.infl[j]) < R.ox[j]) ? (1u << j) : 0u; });
-        }
-        if constexpr (d == 2) {
-          tr.y_min -= ds;
-          t_ymin = 0;
-          CSDO_FOR(j, OBS_NEAR, { t_ymin |= ((tr.y_min - R.infl[j]) < R.oy[j]) ? (1u << j) : 0u; });
-        }
-        if constexpr (d == 3) {
-          tr.x_max += ds;
-          t_xmax = 0;
-          CSDO_FOR(j, OBS_NEAR, { t_xmax |= (R.ox[j] < (tr.x_max + R.infl[j])) ? (1u << j) : 0u; });
-        }
-        bool ok = !(tr.x_min < rv || tr.x_max > dimx - rv || tr.y_min < rv || tr.y_max > dimy - rv) &&
-                  (t_ymax & t_xmin & t_ymin & t_xmax) == 0u;
-        if (ok && R.has_rest) {   // more than OBS_NEAR obstacles near this seed: the others the slow way
-          bool hit = false;
-          CSDO_FOR(w, 4, {
-            unsigned long long m = R.rest.m[w];
-            while (m && !hit) {
-              const int k = 64 * w + ctz64(m);
-              m &= m - 1;
-              hit = obstacle_in_box(tr, obs, n_obs, k, rv);
-            }
-          });
-          for (int k = OBS_MASK_CAP; k < n_obs && !hit; ++k) hit = obstacle_in_box(tr, obs, n_obs, k, rv);
-          ok = !hit;
-        }
-        if (ok) {
-          num_expand++;
-          len[d] += ds;
-          box = tr;
-          s_ymax = t_ymax;
-          s_xmin = t_xmin;
-          s_ymin = t_ymin;
-          s_xmax = t_xmax;
-          if (len[d] >= l_limit) on[d] = false;
-        } else {
-          on[d] = false;
+#if defined(CSDO_GROW_STATS)
+  csdo_grow_stats[0]++;
+#endif
+  // round in which a side's trial fails for a reason of its own: the map border, or the step after the last allowed one
+  int stop0 = 1, stop1 = 1, stop2 = 1, stop3 = 1;
+  {
+    const double x_hi = dimx - rv, y_hi = dimy - rv;
+    if (!(xc < rv || xc > x_hi || yc < rv || yc > y_hi)) {
+#if defined(CSDO_LANE_MODE_DEVICE)
+#pragma nounroll
+#endif
+      for (int d = 0; d < 4; ++d) {
+        int v = first_step(d, xc, yc, (d == 1) ? rv : x_hi, (d == 2) ? rv : y_hi, 0.0);
+        v = v < 1 ? 1 : (v > GROW_LIMIT + 1 ? GROW_LIMIT + 1 : v);
+        if (d == 0) stop0 = v;
+        if (d == 1) stop1 = v;
+        if (d == 2) stop2 = v;
+        if (d == 3) stop3 = v;
+      }
+    }
+  }
+  int st0 = 0, st1 = 0, st2 = 0, st3 = 0;   // accepted steps of the sides that have stopped
+  unsigned moving = 0xFu;
+  bool seed_inside = false;
+  for (int pass = 0; pass < 4 && !seed_inside; ++pass) {
+    // earliest trial that fails, key = 4 * round + side
+    int best = 4 * (GROW_LIMIT + 2);
+    if (moving & 1u) best = 4 * stop0 + 0 < best ? 4 * stop0 + 0 : best;
+    if (moving & 2u) best = 4 * stop1 + 1 < best ? 4 * stop1 + 1 : best;
+    if (moving & 4u) best = 4 * stop2 + 2 < best ? 4 * stop2 + 2 : best;
+    if (moving & 8u) best = 4 * stop3 + 3 < best ? 4 * stop3 + 3 : best;
+    unsigned long long m0 = M.m[0], m1 = M.m[1], m2 = M.m[2], m3 = M.m[3];
+    int k_tail = OBS_MASK_CAP;
+    while ((m0 | m1 | m2 | m3) != 0ull || k_tail < n_obs) {
+      int k;
+      if (m0) {
+        k = ctz64(m0);
+        m0 &= m0 - 1;
+      } else if (m1) {
+        k = 64 + ctz64(m1);
+        m1 &= m1 - 1;
+      } else if (m2) {
+        k = 128 + ctz64(m2);
+        m2 &= m2 - 1;
+      } else if (m3) {
+        k = 192 + ctz64(m3);
+        m3 &= m3 - 1;
+      } else {
+        k = k_tail++;
+      }
+      const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
+      // the stopped sides must have their inequality true where they stopped; among the moving ones the obstacle is entered
+      // in round mx by the last side that attains it
+      bool live = true;
+      int mx = 0, last = 0;
+#if defined(CSDO_LANE_MODE_DEVICE)
+#pragma nounroll
+#endif
+      for (int d = 0; d < 4; ++d) {
+        const int e = first_step(d, xc, yc, ox, oy, infl);
+        const int stopped_at = (d == 0) ? st0 : (d == 1) ? st1 : (d == 2) ? st2 : st3;
+        if (moving & (1u << d)) {
+          if (e >= mx) {
+            mx = e;
+            last = d;
+          }
+        } else if (e > stopped_at) {
+          live = false;
         }
       }
-    });
+      if (live && mx < 1) seed_inside = true;   // every inequality holds at the seed: no trial can succeed
+      const int key = 4 * mx + last;
+      if (live && key < best) best = key;
+    }
+    const int side = best & 3, round = best >> 2;
+    if (side == 0) st0 = round - 1;
+    if (side == 1) st1 = round - 1;
+    if (side == 2) st2 = round - 1;
+    if (side == 3) st3 = round - 1;
+    moving &= ~(1u << side);
+  }
+  if (seed_inside) {   // (only ever found in the first pass: later, an obstacle that holds the box would have stopped a side)
+    res = BoxD{xc, yc, xc, yc};
+    return false;
+  }
+  // replay: the coordinates are the same sums as in the reference's walk
+  BoxD box{xc, yc, xc, yc};
+  for (int n = 1; n <= GROW_LIMIT; ++n) {
+    if (n <= st0) box.y_max += ds;
+    if (n <= st1) box.x_min -= ds;
+    if (n <= st2) box.y_min -= ds;
+    if (n <= st3) box.x_max += ds;
   }
   res = box;
-  return num_expand > 0;
+  return (st0 + st1 + st2 + st3) > 0;
 }
 
 // generateBox, corridor.cc:124-159.  Returns bit0 = success, bits1-2 = initial status (0 legal, 1 out of map,
@@ -553,6 +596,10 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
 // reference's unordered_set iteration order).
 CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double dimx, double dimy, double rv,
                      BoxD& res) {
+#if defined(CSDO_ABL_NOBOX)   // allocation experiment only
+  res = BoxD{x - 1.0, y - 1.0, x + 1.0, y + 1.0};
+  return 1;
+#endif
   int initial = 0;
   if (x < rv || x > dimx - rv || y < rv || y > dimy - rv) {  // isPointOutOfMap + projectNearBorder
     initial = 1;
@@ -570,22 +617,32 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
       break;
     }
   }
-  bool success;
-  if (hit >= 0) {  // generateLegalPoint, corridor.cc:84-122
+  // One call site for the growth: from the point itself, or (generateLegalPoint, corridor.cc:84-122) from up to 20 points on
+  // a circle around the obstacle the point is inside of, alternating sides, until a grown box is valid against every obstacle.
+  bool success = false;
+  double hx = 0.0, hy = 0.0, theta0 = 0.0, d_ring = 0.0;
+  if (hit >= 0) {
     initial = 2;
-    const double hx = obs[hit], hy = obs[n_obs + hit], hr = obs[2 * n_obs + hit];
-    const double theta0 = atan2(y - hy, x - hx);
-    const double d = rv + hr + 0.2;
-    success = false;
-    BoxD cand{x, y, x, y};
-    for (int i = 0; i < 20 && !success; ++i) {
+    hx = obs[hit];
+    hy = obs[n_obs + hit];
+    theta0 = atan2(y - hy, x - hx);
+    d_ring = rv + obs[2 * n_obs + hit] + 0.2;
+  }
+  const int n_try = (hit >= 0) ? 20 : 1;
+  BoxD cand{x, y, x, y};
+  for (int i = 0; i < n_try && !success; ++i) {
+    bool in_map = true;
+    if (hit >= 0) {
       int j = i / 2;
       if (i % 2 == 1) j = -j;
       const double theta = theta0 + j * 2 * M_PI / 20;
-      x = hx + d * cos(theta);
-      y = hy + d * sin(theta);
-      if (x > rv && x < dimx - rv && y > rv && y < dimy - rv) {
-        grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand);
+      x = hx + d_ring * cos(theta);
+      y = hy + d_ring * sin(theta);
+      in_map = x > rv && x < dimx - rv && y > rv && y < dimy - rv;
+    }
+    if (in_map) {
+      const bool grew = grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand);
+      if (hit >= 0) {
         ObsMask all;
         all.m[0] = all.m[1] = all.m[2] = all.m[3] = ~0ull;   // isBoxValid over every obstacle (bits >= n_obs masked below)
         if (n_obs < 256) {
@@ -594,14 +651,14 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
             all.m[w] = (n_obs <= lo_) ? 0ull : ((n_obs - lo_ >= 64) ? ~0ull : ((1ull << (n_obs - lo_)) - 1ull));
           });
         }
-        if (box_valid(cand, obs, n_obs, dimx, dimy, rv, all)) success = true;
+        success = box_valid(cand, obs, n_obs, dimx, dimy, rv, all);
+      } else {
+        success = grew;
       }
     }
-    if (!success) cand = BoxD{x, y, x, y};  // zero-area fallback
-    res = cand;
-  } else {
-    success = grow_box(x, y, obs, n_obs, dimx, dimy, rv, res);
   }
+  if (hit >= 0 && !success) cand = BoxD{x, y, x, y};  // zero-area fallback at the last point tried
+  res = cand;
   return (success ? 1 : 0) | (initial << 1);
 }
 

@@ -877,7 +877,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
     };
 
-    factor(rho);
+    // (one site for the factorisation, at the top of the block loop: every inlined copy of a large cold piece takes part in
+    // the register allocation of the whole program - measured with the box code, dsqp_program.h)
+    bool need_factor = true;
 
     // ============================================================== ADMM (osqp_solve, osqp.c)
     const int max_it = P.osqp_max_iter;
@@ -1196,6 +1198,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     bool finished = false;
     iter = 0;
     while (!finished) {
+      if (need_factor) {
+        factor(rho);
+        need_factor = false;
+      }
       int stop = max_it;
       if (chk) stop = osqp_min_i(stop, (iter / chk + 1) * chk);
       if (P.adaptive_rho_interval) stop = osqp_min_i(stop, (iter / P.adaptive_rho_interval + 1) * P.adaptive_rho_interval);
@@ -1419,7 +1425,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         est = osqp_min(osqp_max(est, RHO_MIN), RHO_MAX);
         if (est > rho * P.adaptive_rho_tolerance || est < rho / P.adaptive_rho_tolerance) {
           rho = uniform_f64(osqp_min(osqp_max(est, RHO_MIN), RHO_MAX));
-          factor(rho);
+          need_factor = true;
         }
       }
     }

@@ -122,10 +122,27 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 #define FA(k, t) SX(78 + (k), t)
 #define FR(k, t) FE(36 + (k), t)
 #define ROW(r, f) (rows + (int64_t)(f) * rcap)[(unsigned)(r)]
+#if defined(CSDO_PROFILE_PHASES)
+struct FactorProf {   // diagnostic build: the caller's phase timers (slots 16..18: assembly, levels, tail inversion)
+  long long* acc;
+  long long* last;
+};
+#define CSDO_FPHASE(k)                                                 \
+  do {                                                                 \
+    if (threadIdx.x == 0) {                                            \
+      const long long now_ = (long long)__builtin_amdgcn_s_memtime();  \
+      fprof.acc[k] += now_ - *fprof.last;                              \
+      *fprof.last = now_;                                              \
+    }                                                                  \
+  } while (0)
+#else
+struct FactorProf {};
+#define CSDO_FPHASE(k) ((void)0)
+#endif
 template <int ROLE, int MODE>
 CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t rcap_in, const int32_t* tstart_in,
                               const int Nt_in, const int h_tail_in, const int n_tail_in, const double sigma_in,
-                              const double rho_in) {
+                              const double rho_in, const FactorProf fprof) {
   const Shm& sh = sh_in;
   const double* rows = rows_in;
   const int64_t rcap = rcap_in;
@@ -200,6 +217,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
   }
   CSDO_SYNC();
+  CSDO_FPHASE(16);
   for (int h = 1; h < h_tail; h <<= 1) {
     const int m2 = 2 * h - 1;
     CSDO_SLANES(t) {  // eliminated nodes
@@ -352,6 +370,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
     CSDO_SYNC();
   }
+  CSDO_FPHASE(17);
   // ---- dense tail: the remaining nodes k * h_tail (k < R_tail) form a block-tridiagonal system with diagonal
   // blocks FA and couplings FR.  It is assembled into LDS (sh.tinv, row r = 6k + i) and inverted in place by
   // Gauss-Jordan elimination without pivoting (the matrix is SPD), one element per thread and pivot step; the rows
@@ -371,34 +390,81 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
   }
   CSDO_SYNC();
-  for (int pv = 0; pv < n_tail; ++pv) {
-    // column pv (the eliminators) and the scaled pivot row go to a side buffer first: the update below overwrites both
-    CSDO_TLANES(t) {
-      const double dinv = 1.0 / SH(tinv, pv, pv);
-      sh.tvec[t] = SH(tinv, pv, t);
-      sh.tvec[TAIL_N + t] = (t == pv) ? dinv : SH(tinv, t, pv) * dinv;
-    }
-    CSDO_SYNC();
-    CSDO_STHREADS(l, nthr) {
-      for (int e = l; e < n_tail * n_tail; e += nthr) {
-        const int r = e / n_tail, c = e - r * n_tail;
-        const double pc = sh.tvec[TAIL_N + c];
-        double v;
-        if (r == pv) {
-          v = pc;
-        } else {
-          const double f = sh.tvec[r];
-          v = (c == pv) ? (-f * pc) : fma(-f, pc, SH(tinv, c, r));
+  // In-place inversion by BLOCK Gauss-Jordan, one 6x6 pivot block per tail node (the pivot blocks of an SPD matrix are SPD:
+  // no pivoting).  Scalar Gauss-Jordan was 36 pivots x 2 barriers of mostly latency (77 k cycles per factorisation); this is
+  // <= 6 block pivots x 3 barriers.  For pivot block P (rows / columns 6p .. 6p+5) and everything else R:
+  //   A[P,R] <- Pinv A[P,R];   A[R,R] <- A[R,R] - A[R,P] A[P,R];   A[R,P] <- -A[R,P] Pinv;   A[P,P] <- Pinv
+  // Pinv of the NEXT pivot is computed by one lane while the column block of the current one is finished.
+  double* const pinv = sh.vec;     // 36 doubles of scratch: the exchange vectors are dead during the factorisation
+  const int n_piv = n_tail / 6;
+  auto pivot_inverse = [&](const int p) __attribute__((always_inline)) {   // one lane: packed lower triangle -> full 6x6 inverse
+    double Ain[21], Pin[21];
+    CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = SH(tinv, 6 * p + c, 6 * p + r); }); });
+    spd_inverse6(Ain, Pin);
+    CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { pinv[r * 6 + c] = Pin[sym(r, c)]; }); });
+  };
+  CSDO_TLANES(t) {
+    if (t == 0) pivot_inverse(0);
+  }
+  CSDO_SYNC();
+  for (int p = 0; p < n_piv; ++p) {
+    const int p0 = 6 * p;
+    CSDO_STHREADS(l, nthr) {   // row block: one thread per column outside the pivot block
+      for (int c = l; c < n_tail; c += nthr) {
+        if (c < p0 || c >= p0 + 6) {
+          double a[6], nw[6];
+          CSDO_FOR(j, 6, { a[j] = SH(tinv, c, p0 + j); });
+          CSDO_FOR(k, 6, {
+            double v = 0.0;
+            CSDO_FOR(j, 6, { v = fma(pinv[k * 6 + j], a[j], v); });
+            nw[k] = v;
+          });
+          CSDO_FOR(k, 6, { SH(tinv, c, p0 + k) = nw[k]; });
         }
-        SH(tinv, c, r) = v;
       }
     }
     CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {   // everything outside the pivot's rows and columns
+      for (int e = l; e < n_tail * n_tail; e += nthr) {
+        const int r = e / n_tail, c = e - r * n_tail;
+        if ((r < p0 || r >= p0 + 6) && (c < p0 || c >= p0 + 6)) {
+          double v = SH(tinv, c, r);
+          CSDO_FOR(k, 6, { v = fma(-SH(tinv, p0 + k, r), SH(tinv, c, p0 + k), v); });
+          SH(tinv, c, r) = v;
+        }
+      }
+    }
+    CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {   // column block and the pivot block itself; lane 0 of the tail inverts the next pivot block
+      for (int r = l; r < n_tail; r += nthr) {
+        double nw[6];
+        if (r < p0 || r >= p0 + 6) {
+          double a[6];
+          CSDO_FOR(j, 6, { a[j] = SH(tinv, p0 + j, r); });
+          CSDO_FOR(k, 6, {
+            double v = 0.0;
+            CSDO_FOR(j, 6, { v = fma(-a[j], pinv[j * 6 + k], v); });
+            nw[k] = v;
+          });
+        } else {
+          CSDO_FOR(k, 6, { nw[k] = pinv[(r - p0) * 6 + k]; });
+        }
+        CSDO_FOR(k, 6, { SH(tinv, p0 + k, r) = nw[k]; });
+      }
+    }
+    CSDO_SYNC();   // (pinv is still being read above: the next pivot's inverse waits for this barrier)
+    if (p + 1 < n_piv) {
+      CSDO_TLANES(t) {
+        if (t == 0) pivot_inverse(p + 1);
+      }
+      CSDO_SYNC();
+    }
   }
   CSDO_TLANES(t) {
     if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });
   }
   CSDO_SYNC();
+  CSDO_FPHASE(18);
 }
 #undef FA
 #undef FR
@@ -708,7 +774,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     auto factor = [&](const double rho_now) __attribute__((always_inline)) {
       CSDO_MARK("factor_begin");
       CSDO_PHASE(5);
-      bcr_factor<ROLE, MODE>(sh, rows, rcap, tstart, Nt, h_tail, n_tail, sigma, rho_now);
+#if defined(CSDO_PROFILE_PHASES)
+      const FactorProf fprof{prof_acc, &prof_last};
+#else
+      const FactorProf fprof{};
+#endif
+      bcr_factor<ROLE, MODE>(sh, rows, rcap, tstart, Nt, h_tail, n_tail, sigma, rho_now, fprof);
     };
 
     // ============================================================== BCR solve on the solver lanes.

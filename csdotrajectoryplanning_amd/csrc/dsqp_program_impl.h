@@ -235,7 +235,18 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           // LDS as they are produced and read back column by column, so that one 6x6 operand, the pivot inverse and a
           // handful of accumulators are all that is live (the all-register version below spills, and a spilled double
           // costs an L2 round trip).  Same products, same summation order, same results.
-#define STASH(k) SH(stash, k, t)
+          // MODE 0: the exchange of a level goes through LDS.  The ADMM block's per-timestep arrays (vec .. fx, 80 doubles per
+          // timestep, contiguous) are dead during the factorisation; seen as 80 fields x stride they give every node a
+          // column.  An eliminated node parks its products in its own column and DELIVERS its Schur complements into the
+          // columns of the two surviving neighbours, which are idle at this level: fields 0..20 <- U_r of the left
+          // neighbour, 21..41 <- U_l of the right neighbour, 42..77 <- the new coupling from the right neighbour.  (Through
+          // the workspace the absorption alone was 19 k cycles per level: the workspaces of the 32 agents of an XCD do not
+          // fit its L2, so the exchange went to HBM and back.)
+#define XC(k, tt) sh.vec[(size_t)(k) * sh.stride + (unsigned)(tt)]
+#define STASH(k) (*((MODE == 0) ? &XC(k, t) : &SH(stash, k, t)))
+#define PUT_UL(idx, v) (*((MODE == 0) ? &XC(21 + (idx), t - h) : &SX(idx, t)) = (v))
+#define PUT_CPL(idx, v) (*((MODE == 0) ? &XC(42 + (idx), t - h) : &SX(42 + (idx), t)) = (v))
+#define PUT_UR(idx, v) (*((MODE == 0) ? &XC(idx, t + h) : &SX(21 + (idx), t)) = (v))
           {
             double Rl[36];
             CSDO_FOR(k, 36, { Rl[k] = FR(k, t - h); });
@@ -255,7 +266,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 if constexpr (a_ >= b_) {
                   double a = 0.0;
                   CSDO_FOR(k, 6, { a = fma(Rl[k * 6 + a_], tc[k], a); });
-                  SX(sym(a_, b_), t) = a;
+                  PUT_UL(sym(a_, b_), a);
                 }
               });
             });
@@ -270,7 +281,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
               CSDO_FOR(a_, 6, {
                 double a = 0.0;
                 CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], tc[k], a); });
-                SX(42 + a_ * 6 + b_, t) = -a;
+                PUT_CPL(a_ * 6 + b_, -a);
               });
             });
             CSDO_STAGE();
@@ -289,7 +300,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 if constexpr (a_ >= b_) {
                   double a = 0.0;
                   CSDO_FOR(k, 6, { a = fma(Rr[a_ * 6 + k], vc[k], a); });
-                  SX(21 + sym(a_, b_), t) = a;
+                  PUT_UR(sym(a_, b_), a);
                 }
               });
             });
@@ -297,6 +308,9 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
             CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = STASH(r * 6 + c); }); });
           }
 #undef STASH
+#undef PUT_UL
+#undef PUT_CPL
+#undef PUT_UR
         } else {
           // T = Sinv * Rl   (rows: own vars, cols: left node's vars) = F_l, what the solve uses
           double T[36];
@@ -355,20 +369,31 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       }
     }
     CSDO_SYNC();
+    CSDO_FPHASE(19);
     CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements and take the coupling to their new right neighbour
       if ((t & m2) == 0) {
         double A[21];
         CSDO_FOR(k, 21, { A[k] = FA(k, t); });
-        if (t >= h) CSDO_FOR(k, 21, { A[k] -= SX(21 + k, t - h); });
-        if ((t + h) < Nt) {
-          CSDO_FOR(k, 21, { A[k] -= SX(k, t + h); });
-          const bool has_rr = (t + 2 * h) < Nt;
-          CSDO_FOR(k, 36, { FR(k, t) = has_rr ? SX(42 + k, t + h) : 0.0; });
+        if constexpr (MODE == 0) {   // delivered into this node's own column (see the elimination above)
+          if (t >= h) CSDO_FOR(k, 21, { A[k] -= XC(k, t); });
+          if ((t + h) < Nt) {
+            CSDO_FOR(k, 21, { A[k] -= XC(21 + k, t); });
+            const bool has_rr = (t + 2 * h) < Nt;
+            CSDO_FOR(k, 36, { FR(k, t) = has_rr ? XC(42 + k, t) : 0.0; });
+          }
+        } else {
+          if (t >= h) CSDO_FOR(k, 21, { A[k] -= SX(21 + k, t - h); });
+          if ((t + h) < Nt) {
+            CSDO_FOR(k, 21, { A[k] -= SX(k, t + h); });
+            const bool has_rr = (t + 2 * h) < Nt;
+            CSDO_FOR(k, 36, { FR(k, t) = has_rr ? SX(42 + k, t + h) : 0.0; });
+          }
         }
         CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
       }
     }
     CSDO_SYNC();
+    CSDO_FPHASE(17);
   }
   CSDO_FPHASE(17);
   // ---- dense tail: the remaining nodes k * h_tail (k < R_tail) form a block-tridiagonal system with diagonal
@@ -468,6 +493,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
 }
 #undef FA
 #undef FR
+#undef XC
 #undef ROW
 
 // =========================================================================================================

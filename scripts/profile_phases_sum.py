@@ -30,8 +30,8 @@ for label, sel in (("all agents", it >= 0), ("short agents (< 1000 iterations)",
         label, sel.sum(), it[sel].sum(), sq[sel].sum(), tk[sel].sum() * 1e-5, tk[sel].sum() * 1e-2 / max(it[sel].sum(), 1), tk[sel].sum() * 1e-5 / max(sq[sel].sum(), 1)))
     print("   " + "  ".join("%s %.1f%%" % (n, 100.0 * p[i] / tot) for i, n in enumerate(NAMES[:15])))
     print("   cycles per SQP iteration: " + "  ".join("%s %.0fk" % (NAMES[i], p[i] / max(sq[sel].sum(), 1) / 1e3) for i in (1, 2, 3, 4, 5, 10, 11, 12)))
-    fsub = ph[sel][:, 24:27].sum(0).astype(float)    # factor sub-phases (slots 16..18 of the kernel's timers)
-    print("   factor, cycles per SQP iteration: assembly %.0fk  levels %.0fk  tail inversion %.0fk  (the factor column above counts only the rest)" % tuple(fsub / max(sq[sel].sum(), 1) / 1e3))
+    fsub = ph[sel][:, 24:28].sum(0).astype(float)    # factor sub-phases (slots 16..19 of the kernel's timers)
+    print("   factor, cycles per SQP iteration: assembly %.0fk  levels: elimination %.0fk + absorption %.0fk  tail inversion %.0fk  (the factor column above counts only the rest)" % tuple(fsub[[0, 3, 1, 2]] / max(sq[sel].sum(), 1) / 1e3))
     n_it = max(it[sel].sum(), 1)
     print("   cycles per ADMM iteration: " + "  ".join("%s %.0f" % (NAMES[i], p[i] / n_it) for i in (6, 7, 13, 8, 14, 9)) +
           "  | iteration total %.0f" % (sum(p[i] for i in (6, 7, 13, 8, 14, 9)) / n_it))

@@ -616,6 +616,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   CSDO_PHASE(2);
     // ============================================================== assemble the QP (unscaled)
     CSDO_MARK("assemble");
+    // The inter-vehicle rows' coefficients and scalings are read and rewritten row by row in each of the ten equilibration
+    // passes.  In the workspace every such access is a trip to HBM (the workspaces of the agents sharing an XCD do not fit
+    // its L2) and the rows of a timestep are a serial chain: 40 k cycles per pass.  During the set-up stages the ADMM
+    // block's LDS arrays are idle, so the four fields live in the `fx` part of them (fields x 4K rows) whenever they fit, and
+    // the warm-start stage publishes them to the workspace.
+    const bool rz_lds = (MODE == 0) && ((int64_t)16 * ad.n_planes <= (int64_t)LD_fx * sh.stride);
+    auto rz = [&](const int r, const int f_lds, const int f_ws) __attribute__((always_inline)) -> double& {
+      return rz_lds ? sh.fx[(size_t)f_lds * (size_t)rcap + (unsigned)r] : ROW(r, f_ws);
+    };
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       double dfx, dfy, drx, dry, exf, eyf, exr, eyr;
@@ -629,11 +638,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           const double Dx = (r < 2) ? dfx : drx, Dy = (r < 2) ? dfy : dry;
           const double Ex = (r < 2) ? exf : exr, Ey = (r < 2) ? eyf : eyr;
           const int rr = 4 * k + r;
-          ROW(rr, R_CA) = a;
-          ROW(rr, R_CB) = bb;
-          ROW(rr, R_CY) = a * Dx + bb * Dy;
+          rz(rr, 0, R_CA) = a;
+          rz(rr, 1, R_CB) = bb;
+          rz(rr, 2, R_CY) = a * Dx + bb * Dy;
           ROW(rr, R_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
-          ROW(rr, R_E) = 1.0;
+          rz(rr, 3, R_E) = 1.0;
         });
       }
     }
@@ -675,20 +684,20 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           Et[i] = 1.0 / sqrt(limit_scaling(rn));
         });
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          cn_[0] = dmax(cn_[0], fabs(ROW(r, R_CA)));
-          cn_[1] = dmax(cn_[1], fabs(ROW(r, R_CB)));
-          cn_[2] = dmax(cn_[2], fabs(ROW(r, R_CY)));
+          cn_[0] = dmax(cn_[0], fabs(rz(r, 0, R_CA)));
+          cn_[1] = dmax(cn_[1], fabs(rz(r, 1, R_CB)));
+          cn_[2] = dmax(cn_[2], fabs(rz(r, 2, R_CY)));
         }
         CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_scaling(cn_[j])) : 1.0; });
         // inter rows only touch own columns: scale them now
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double a = ROW(r, R_CA), bb = ROW(r, R_CB), cy = ROW(r, R_CY);
+          const double a = rz(r, 0, R_CA), bb = rz(r, 1, R_CB), cy = rz(r, 2, R_CY);
           const double rn = dmax(dmax(fabs(a), fabs(bb)), fabs(cy));
           const double et = 1.0 / sqrt(limit_scaling(rn));
-          ROW(r, R_CA) = (a * et) * Dt[0];
-          ROW(r, R_CB) = (bb * et) * Dt[1];
-          ROW(r, R_CY) = (cy * et) * Dt[2];
-          ROW(r, R_E) = ROW(r, R_E) * et;
+          rz(r, 0, R_CA) = (a * et) * Dt[0];
+          rz(r, 1, R_CB) = (bb * et) * Dt[1];
+          rz(r, 2, R_CY) = (cy * et) * Dt[2];
+          rz(r, 3, R_E) = rz(r, 3, R_E) * et;
         }
         CSDO_FOR(k, 5, { SH(carry2, k, t) = Dt[k]; });
       }
@@ -755,7 +764,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       WS(W_ACT, t) = (double)S.act;
       WS(W_EQ, t) = (double)eq;
       WS(W_LOOSE, t) = (double)loose;
-      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) ROW(r, R_U) = ROW(r, R_E) * ROW(r, R_U);
+      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) ROW(r, R_U) = rz(r, 3, R_E) * ROW(r, R_U);
       // osqp_warm_start_x: x <- Dinv x0
       CSDO_FOR(j, 6, { S.x[j] = (1.0 / CD(C_D + j, t)) * CD(C_SOL0 + j, t); });
       CSDO_FOR(k, 4, { SH(carry2, k, t) = S.x[k]; });
@@ -773,9 +782,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CD(C_DY + i, t) = 0.0;
       });
       for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-        ROW(r, R_Z) = (ROW(r, R_CA) * S.x[0] + ROW(r, R_CB) * S.x[1]) + ROW(r, R_CY) * S.x[2];
+        const double a = rz(r, 0, R_CA), bb = rz(r, 1, R_CB), cy = rz(r, 2, R_CY);
+        ROW(r, R_Z) = (a * S.x[0] + bb * S.x[1]) + cy * S.x[2];
         ROW(r, R_Y) = 0.0;
         ROW(r, R_DY) = 0.0;
+        if (rz_lds) {   // publish what the set-up stages kept in LDS
+          ROW(r, R_CA) = a;
+          ROW(r, R_CB) = bb;
+          ROW(r, R_CY) = cy;
+          ROW(r, R_E) = rz(r, 3, R_E);
+        }
       }
       // the set-up stage worked in registers; publish the master copy for the cold phases and for load_hot
       CSDO_FOR(i, NROW, {

@@ -879,24 +879,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               });
               CSDO_FOR(arow, 6, { SH(pr, arow, t) = qa[arow] + qb[arow]; });
             }
-            CSDO_STAGE();
-            // w = Sinv b, three rows at a time: 15 of the 21 packed entries and 9 accumulation chains are live at once
-            // (with all 21 + 12 chains beside the 72 doubles of couplings the allocator spills a third of the factor)
-            double w6[6];
-            CSDO_FOR(half, 2, {
-              double sv[6][6];
-              CSDO_FOR(r3, 3, {
-                CSDO_FOR(c, 6, { sv[r3][c] = SINV(sym(3 * half + r3, c), t); });
-              });
-              CSDO_FOR(r3, 3, {
-                const double s01 = fma(sv[r3][1], bb[1], sv[r3][0] * bb[0]);
-                const double s23 = fma(sv[r3][3], bb[3], sv[r3][2] * bb[2]);
-                const double s45 = fma(sv[r3][5], bb[5], sv[r3][4] * bb[4]);
-                w6[3 * half + r3] = (s01 + s23) + s45;
-              });
-              CSDO_STAGE();
-            });
-            CSDO_FOR(k, 6, { V.b[k] = w6[k]; });
+            // (w = Sinv b is only needed by the backward sweep: every eliminated node computes it in ONE pass behind the
+            // last level, while the tail nodes gather - inside the levels it cost each of them ~400 cycles of critical path)
             CSDO_LVL_END(lvl_fwd);
           }
         }
@@ -908,6 +892,26 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // of the explicit inverse with it and scatters the solution straight into the nodes' vec slots
       CSDO_SLANES(t) {
         SolvRegs& V = CSDO_SS(t);
+        if ((t & (h_tail - 1)) != 0) {
+          // w = Sinv b of every eliminated node, three rows at a time: 15 of the 21 packed entries and 9 accumulation chains
+          // are live at once (with all 21 + 12 chains beside the couplings the allocator spills a third of the factor)
+          double bb[6], w6[6];
+          CSDO_FOR(k, 6, { bb[k] = V.b[k]; });
+          CSDO_FOR(half, 2, {
+            double sv[6][6];
+            CSDO_FOR(r3, 3, {
+              CSDO_FOR(c, 6, { sv[r3][c] = SINV(sym(3 * half + r3, c), t); });
+            });
+            CSDO_FOR(r3, 3, {
+              const double s01 = fma(sv[r3][1], bb[1], sv[r3][0] * bb[0]);
+              const double s23 = fma(sv[r3][3], bb[3], sv[r3][2] * bb[2]);
+              const double s45 = fma(sv[r3][5], bb[5], sv[r3][4] * bb[4]);
+              w6[3 * half + r3] = (s01 + s23) + s45;
+            });
+            CSDO_STAGE();
+          });
+          CSDO_FOR(k, 6, { V.b[k] = w6[k]; });
+        }
         if ((t & (h_tail - 1)) == 0) {
           if (h_tail > 1) {
             const int hp = h_tail >> 1;

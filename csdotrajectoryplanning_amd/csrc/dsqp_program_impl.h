@@ -884,7 +884,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             CSDO_LVL_END(lvl_fwd);
           }
         }
-        CSDO_PHASE(13);
+        CSDO_PHASE(h == 1 ? 20 : 13);   // (diagnostic build: the first interval also holds the rhs assembly)
         CSDO_SYNC();
         CSDO_PHASE(7);
       }
@@ -922,7 +922,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(k, 6, { sh.tvec[6 * kn + k] = V.b[k]; });
         }
       }
+      CSDO_PHASE(21);
       CSDO_SYNC();
+      CSDO_PHASE(22);
       CSDO_TLANES(t) {
         {
           // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed

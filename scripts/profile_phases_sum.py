@@ -35,6 +35,8 @@ for label, sel in (("all agents", it >= 0), ("short agents (< 1000 iterations)",
     n_it = max(it[sel].sum(), 1)
     print("   cycles per ADMM iteration: " + "  ".join("%s %.0f" % (NAMES[i], p[i] / n_it) for i in (6, 7, 13, 8, 14, 9)) +
           "  | iteration total %.0f" % (sum(p[i] for i in (6, 7, 13, 8, 14, 9)) / n_it))
+    sub = ph[sel][:, 28:31].sum(0).astype(float) / n_it    # slots 20..22
+    print("   of the forward sweep, per ADMM iteration: rhs assembly + first level %.0f  |  w pass + tail gather %.0f  |  tail product %.0f" % tuple(sub))
     # per-level cycles inside the elimination block of solver lane t = 2^lv (forward / backward), per ADMM iteration of the
     # agents that have that level
     fw = ph[sel][:, 16:24].astype(float); bw = ph[sel][:, 32:40].astype(float)

@@ -148,6 +148,17 @@ static int build_groups(csdo_handle h) {
     g.max_nt = std::max(g.max_nt, (int)hb.agents[a].Nt);
     g.lds_bytes = std::max(g.lds_bytes, need[a]);
   }
+  // The planes' read-only coefficients take whatever LDS a launch has left (Shm::pco): a group with inter-vehicle rows in LDS
+  // asks for everything its class may use (80 KB for the class that runs two workgroups per CU, 160 KB otherwise).
+  for (LaunchGroup& g : h->groups) {
+    bool any = false;
+    for (int i = 0; i < g.count && !any; ++i) {
+      const AgentDesc& ad = hb.agents[h->order[g.first + i]];
+      any = ad.rows_lds != 0 && ad.n_planes > 0;
+    }
+    if (any && g.mode == 0 && g.lds_bytes <= dsqp_lds_capacity())
+      g.lds_bytes = dsqp_workgroups_per_cu(g.block, g.lds_bytes) == 2 ? dsqp_lds_capacity_two_per_cu() : dsqp_lds_capacity();
+  }
   while (h->side.size() + 1 < h->groups.size()) {
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CSDO_EDEVICE;

@@ -47,6 +47,7 @@ size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) 
 constexpr size_t LDS_CAP = 160 * 1024 - 64;   // 160 KB per workgroup minus the kernel's static LDS (queue slot)
 constexpr size_t LDS_CAP_2WG = 80 * 1024 - 64;   // two workgroups of the 256-thread class per CU
 size_t dsqp_lds_capacity() { return LDS_CAP; }
+size_t dsqp_lds_capacity_two_per_cu() { return LDS_CAP_2WG; }
 int dsqp_workgroups_per_cu(int block, size_t lds_bytes) { return (block == 256 && lds_bytes <= LDS_CAP_2WG) ? 2 : 1; }
 
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) {

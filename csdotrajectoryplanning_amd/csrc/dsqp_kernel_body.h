@@ -20,7 +20,7 @@ __device__ __forceinline__ T* aligned16(T* p) {
 }
 
 template <int MODE>
-__device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, double* lds) {
+__device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, double* lds, const int lds_doubles) {
   const int ad_Nt = uniform_i32(B.agents[agent].Nt);
   const long long ad_fac_off = uniform_i64(B.agents[agent].fac_off);
   const long long ad_rows_off = uniform_i64(B.agents[agent].rows_off);
@@ -66,8 +66,18 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
     const int n_pc_pad = 2 * ((3 * ad_n_planes + 1) >> 1);
     sh.pc = aligned16(rest);
     sh.prow = aligned16(sh.pc + n_pc_pad);
+    sh.pco = aligned16(sh.prow + (size_t)LD_prow * ad_n_planes);
+    sh.n_pco = sh.n_pco_ld = 0;
+    if (uniform_i32(B.agents[agent].rows_lds) != 0) {   // (the launch sized the LDS for pc / prow of such agents)
+      const int left = lds_doubles - (int)(sh.pco - lds) - 2;
+      int fit = left > 0 ? left / 16 : 0;
+      fit &= ~1;
+      sh.n_pco = fit < ad_n_planes ? fit : ad_n_planes;
+      sh.n_pco_ld = 2 * ((sh.n_pco + 1) >> 1);
+    }
   } else {
-    sh.pc = sh.prow = nullptr;
+    sh.pc = sh.prow = sh.pco = nullptr;
+    sh.n_pco = sh.n_pco_ld = 0;
   }
   double* fac_global = B.fac_ws + ad_fac_off;
   sh.facE = fac_global;
@@ -85,7 +95,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
 // set (<= 80 KB of LDS, 256 registers per lane) allows it.  The 512-thread class fills the register file by itself.
 template <int BLOCK, int MODE, bool SPLIT>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kernel(const DeviceBatch B, const int first, const int count,
-                                                             int* __restrict__ queue) {
+                                                             int* __restrict__ queue, const int lds_doubles) {
   extern __shared__ __align__(16) double lds[];
   __shared__ int next_in_queue;
   static_assert(SPLIT, "one thread per timestep playing both roles is only built lane-serially (tests/emu)");
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
         B.prof[(int64_t)agent * 48 + 46] = ((long long)(xcc & 0xf) << 32) | hw;
       }
 #endif
-      const Shm sh = carve_lds<MODE>(B, agent, lds);
+      const Shm sh = carve_lds<MODE>(B, agent, lds, lds_doubles);
       ProgramOut po;
       RowRegs lr;
       SolvRegs ls_unused;
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
       __syncthreads();
       if (q_idx >= count) break;
       const int agent = uniform_i32(B.order[first + q_idx]);
-      const Shm sh = carve_lds<MODE>(B, agent, lds);
+      const Shm sh = carve_lds<MODE>(B, agent, lds, lds_doubles);
       ProgramOut po;
       RowRegs lr_unused;
       SolvRegs ls;
@@ -140,7 +150,8 @@ hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, int workgr
   auto kernel = dsqp_agent_kernel<BLOCK, MODE, SPLIT>;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(BLOCK), g.lds_bytes, stream, B, g.first, g.count, g.queue);
+  hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(BLOCK), g.lds_bytes, stream, B, g.first, g.count, g.queue,
+                     (int)(g.lds_bytes / sizeof(double)));
   return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ struct LaunchGroup {
 };
 size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds);   // LDS working set of one agent
 int dsqp_workgroups_per_cu(int block, size_t lds_bytes);            // persistent workgroups of a launch group one CU holds
+size_t dsqp_lds_capacity_two_per_cu();                             // ... of the class that runs two workgroups per CU
 size_t dsqp_lds_capacity();                                        // dynamic LDS one workgroup may ask for
 // kernel class of one agent: returns the workgroup size, sets the residency mode and whether the rows' state fits LDS
 int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds);

@@ -287,6 +287,10 @@ struct Shm {
   double* pcg;      // [K][3]  the same in the workspace (all other agents)
   double* prow;     // [K][10] rows_lds: duals, slacks (y[4], z[4]) and timestep of a plane's four inter-vehicle rows during
                     //              an ADMM block
+  double* pco;      // [16][n_pco_ld] rows_lds: coefficients a, b, c_yaw and upper bounds of the four rows of the first n_pco planes
+                    // during an ADMM block, in whatever LDS the launch has left (read-only there; from the workspace they
+                    // were an HBM round trip in every iteration's plane pass)
+  int n_pco, n_pco_ld;
   int stride;
 };
 

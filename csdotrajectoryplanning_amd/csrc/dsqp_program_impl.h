@@ -1258,6 +1258,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #define PC_L(k, p) sh.pc[(p) * 3 + (k)]
 #define PC_G(k, p) sh.pcg[(p) * 3 + (k)]
 #define PROW(f, p) sh.prow[(p) * LD_prow + (f)]   // f: 0..3 y, 4..7 z, 8 timestep
+#define PCO(f, p) sh.pco[(size_t)(f) * sh.n_pco_ld + (p)]
     auto plane_pass = [&](auto update_c, auto keep_c, auto lds_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
       constexpr bool KEEP = decltype(keep_c)::value;
@@ -1273,11 +1274,22 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             zz[q] = ROW(4 * p + q, R_Z);
             yy[q] = ROW(4 * p + q, R_Y);
           }
-          ca[q] = ROW(4 * p + q, R_CA);
-          cb[q] = ROW(4 * p + q, R_CB);
-          cy[q] = ROW(4 * p + q, R_CY);
-          if constexpr (UPDATE) uu[q] = ROW(4 * p + q, R_U);
         });
+        if (ROWS_LDS && UPDATE && p < sh.n_pco) {   // the block's copy of the read-only coefficients (Shm::pco)
+          CSDO_FOR(q, 4, {
+            ca[q] = PCO(q, p);
+            cb[q] = PCO(4 + q, p);
+            cy[q] = PCO(8 + q, p);
+            uu[q] = PCO(12 + q, p);
+          });
+        } else {
+          CSDO_FOR(q, 4, {
+            ca[q] = ROW(4 * p + q, R_CA);
+            cb[q] = ROW(4 * p + q, R_CB);
+            cy[q] = ROW(4 * p + q, R_CY);
+            if constexpr (UPDATE) uu[q] = ROW(4 * p + q, R_U);
+          });
+        }
         if constexpr (UPDATE) {
           int tp;
           if constexpr (ROWS_LDS) tp = (int)PROW(8, p);
@@ -1396,6 +1408,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               PROW(4 + q, p) = ROW(4 * p + q, R_Z);
             });
             PROW(8, p) = (double)planes[p].t;
+          }
+          for (int p = l; p < sh.n_pco; p += nthr) {
+            CSDO_FOR(q, 4, {
+              PCO(q, p) = ROW(4 * p + q, R_CA);
+              PCO(4 + q, p) = ROW(4 * p + q, R_CB);
+              PCO(8 + q, p) = ROW(4 * p + q, R_CY);
+              PCO(12 + q, p) = ROW(4 * p + q, R_U);
+            });
           }
           plane_pass(std::false_type{}, std::false_type{}, std::true_type{}, l, nthr, rho);
         }

@@ -55,7 +55,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     // the same carve as dsqp_kernel_body.h (mode 0: bounds + the factor's LDS part in "LDS", rows' state too when
     // AgentDesc::rows_lds; 1: without the factor part; 3: lean)
     std::vector<double> lds((size_t)80 * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N + TAIL_N * 38 +
-                            (size_t)(3 + LD_prow) * hb.max_planes + 4, 0.0);
+                            (size_t)(3 + LD_prow) * hb.max_planes + 4 + 16 * 8, 0.0);
     std::vector<double> pc_ws((size_t)3 * hb.max_planes + 1, 0.0);
     Shm sh{};
     sh.stride = st;
@@ -87,6 +87,9 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     if (mode == 0) {
       sh.pc = sh.tinv + TAIL_N * 38;
       sh.prow = sh.pc + ((3 * hb.max_planes + 1) & ~1);
+      sh.pco = sh.prow + (size_t)LD_prow * hb.max_planes;   // room for the coefficients of 8 planes: both paths of the
+      sh.n_pco = std::min<int>(8, ad.n_planes) & ~1;         // plane pass (LDS copy / workspace) run in every test
+      sh.n_pco_ld = sh.n_pco;
     }
     sh.facE = fac_ws.data() + ad.fac_off;
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;

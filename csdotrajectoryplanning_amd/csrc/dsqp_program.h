@@ -66,6 +66,10 @@ __device__ __forceinline__ int csdo_opaque(int v) {
   if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
 #define CSDO_TLANES_HOT(t) \
   if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
+// the same 36 lanes taken from the LAST wave of the workgroup: with Nt <= BLOCK/2 - 64 that wave owns no timestep, so what it
+// does runs beside the other solver waves' work instead of in front of it
+#define CSDO_TLANES_TOP(t) \
+  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - ((int)blockDim.x - 64); t >= 0 && t < n_tail)
 #define CSDO_STHREADS_HOT(t, nthr)                                                          \
   if constexpr (ROLE != ROLE_ROW)                                                           \
     if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
@@ -102,6 +106,7 @@ __device__ __forceinline__ int csdo_opaque(int v) {
 #define CSDO_LANES_HOT(t) CSDO_LANES(t)
 #define CSDO_SLANES_HOT(t) CSDO_SLANES(t)
 #define CSDO_TLANES_HOT(t) CSDO_TLANES(t)
+#define CSDO_TLANES_TOP(t) CSDO_TLANES(t)
 #define CSDO_STHREADS_HOT(t, nthr) CSDO_STHREADS(t, nthr)
 #define CSDO_LS(t) lanes_r[t]
 #define CSDO_SS(t) lanes_s[t]

@@ -892,6 +892,38 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // of the explicit inverse with it and scatters the solution straight into the nodes' vec slots
       CSDO_SLANES(t) {
         SolvRegs& V = CSDO_SS(t);
+        if ((t & (h_tail - 1)) == 0) {
+          if (h_tail > 1) {
+            const int hp = h_tail >> 1;
+            if (t >= hp) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - hp); });
+            if ((t + hp) < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + hp); });
+          }
+          const int kn = t / h_tail;
+          CSDO_FOR(k, 6, { sh.tvec[6 * kn + k] = V.b[k]; });
+        }
+      }
+      CSDO_PHASE(21);
+      CSDO_SYNC();
+      CSDO_PHASE(22);
+      CSDO_TLANES_TOP(t) {
+        {
+          // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed
+          double a4[6] = {0, 0, 0, 0, 0, 0};
+          CSDO_FOR(q, 4, {     // quarters of the row: the solver lanes' registers hold their node's factor
+            double tr[TAIL_N / 4], tb[TAIL_N / 4];
+            CSDO_FOR(c, TAIL_N / 4, {
+              tr[c] = SH(tinv, q * (TAIL_N / 4) + c, t);
+              tb[c] = sh.tvec[q * (TAIL_N / 4) + c];
+            });
+            CSDO_FOR(c, TAIL_N / 4, { a4[(q * (TAIL_N / 4) + c) % 6] = fma(tr[c], tb[c], a4[(q * (TAIL_N / 4) + c) % 6]); });
+            CSDO_STAGE();
+          });
+          const int kn = t / 6, i = t - 6 * kn;
+          sh.vec[(kn * h_tail) * LD_vec + i] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + (a4[4] + a4[5]);
+        }
+      }
+      CSDO_SLANES(t) {   // beside the tail product (which runs on the workgroup's last wave): w of the eliminated nodes
+        SolvRegs& V = CSDO_SS(t);
         if ((t & (h_tail - 1)) != 0) {
           // w = Sinv b of every eliminated node, three rows at a time: 15 of the 21 packed entries and 9 accumulation chains
           // are live at once (with all 21 + 12 chains beside the couplings the allocator spills a third of the factor)
@@ -911,35 +943,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             CSDO_STAGE();
           });
           CSDO_FOR(k, 6, { V.b[k] = w6[k]; });
-        }
-        if ((t & (h_tail - 1)) == 0) {
-          if (h_tail > 1) {
-            const int hp = h_tail >> 1;
-            if (t >= hp) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - hp); });
-            if ((t + hp) < Nt) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + hp); });
-          }
-          const int kn = t / h_tail;
-          CSDO_FOR(k, 6, { sh.tvec[6 * kn + k] = V.b[k]; });
-        }
-      }
-      CSDO_PHASE(21);
-      CSDO_SYNC();
-      CSDO_PHASE(22);
-      CSDO_TLANES(t) {
-        {
-          // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed
-          double a4[6] = {0, 0, 0, 0, 0, 0};
-          CSDO_FOR(q, 4, {     // quarters of the row: the solver lanes' registers hold their node's factor
-            double tr[TAIL_N / 4], tb[TAIL_N / 4];
-            CSDO_FOR(c, TAIL_N / 4, {
-              tr[c] = SH(tinv, q * (TAIL_N / 4) + c, t);
-              tb[c] = sh.tvec[q * (TAIL_N / 4) + c];
-            });
-            CSDO_FOR(c, TAIL_N / 4, { a4[(q * (TAIL_N / 4) + c) % 6] = fma(tr[c], tb[c], a4[(q * (TAIL_N / 4) + c) % 6]); });
-            CSDO_STAGE();
-          });
-          const int kn = t / 6, i = t - 6 * kn;
-          sh.vec[(kn * h_tail) * LD_vec + i] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + (a4[4] + a4[5]);
         }
       }
       CSDO_SYNC();

@@ -9,11 +9,13 @@ its ADMM QPs) over one batch of worlds whose inputs are already resident in HBM.
            map50      (configs[1]) the 60 instances of map50by50/agents25/obstacle, 1500 agents
            synth1024  (configs[4]) 21 worlds (ex0..ex20 of the map100 set) truncated to 1024 agents
 N > 1 ranks (torch.distributed.run, one process per GPU, RCCL):
---scaling strong      (default) the batch's agents are SHARDED: rank r owns one contiguous block of the concatenated
-                      agents (csdotrajectoryplanning_amd/sharding.py; agents are independent once their planes are
-                      fixed, sqp/dsqp_solver.cc:1198-1220), solves it, and the step ends with the path's only
-                      collective, the all-gather of the final trajectories on the device pointer
-          weak        every rank owns a whole copy of the workload (its stand-in worlds seeded differently per rank)
+Either way the agents of the job are SHARDED by sharding.shard_batch_plan: rank r owns one contiguous block of the job's
+concatenated agents (the reference's loop over agents is what shards, sqp/dsqp_solver.cc:1198-1220), builds only the worlds
+its block overlaps, solves its block, and the step ends with the path's only collective, the all-gather of the final
+trajectories on the device pointer.
+--scaling weak        (default) the job is N copies of the workload (the stand-in worlds of copy c seeded with 60 c): the
+                      per-GPU work is fixed as N grows
+--scaling strong      the job is ONE copy of the workload whatever N: bounded by its longest agent (47 ms against 88 ms / N)
 Rank 0 prints ONE JSON line.
 
 metric  = agent-QP-iterations/sec: ADMM iterations executed by all agents of all ranks / wall time of the K steps (max
@@ -113,8 +115,8 @@ def main():
     ap.add_argument("--front", choices=("auto", "stand-in"), default="auto",
                     help="initial guesses: the front end's stored paths where it solves the instance (auto, default) or the "
                          "seeded stand-in for every instance (the round-1 workload, for like-for-like comparisons)")
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
-                    help="N > 1: shard the batch's agents over the ranks (strong) or one whole copy per rank (weak)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: the sharded job is N copies of the workload (weak, default) or one copy (strong)")
     ap.add_argument("--instances", type=int, default=None, help="instances of the set (default: the whole set)")
     ap.add_argument("--setup-procs", type=int, default=32, help="processes building the worlds (1: in-process, no fork; "
                                                                   "use that under rocprofv3)")
@@ -129,6 +131,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     strong = world_size > 1 and args.scaling == "strong"
+    copies = 1 if (strong or world_size == 1) else world_size
 
     # torch first: it brings its own HIP runtime, which must be the one libcsdo_hip.so binds to (loading the library
     # before torch puts two runtimes into the process and aborts under rocprofv3); importing does not touch the GPU
@@ -138,10 +141,11 @@ def main():
     from multiprocessing import get_context
     from csdotrajectoryplanning_amd import sharding, workloads
     t_pre0 = time.perf_counter()
-    jobs = workloads.workload_jobs(args.workload, args.instances, seed_offset=0 if (strong or world_size == 1) else 60 * rank,
-                                   front=args.front)
+    jobs = []
+    for c in range(copies):
+        jobs += workloads.workload_jobs(args.workload, args.instances, seed_offset=60 * c, front=args.front)
     sizes = [workloads.job_agents(j) for j in jobs]
-    if strong:   # this rank only builds the worlds its block of agents overlaps
+    if world_size > 1:   # this rank only builds the worlds its block of agents overlaps
         plan = sharding.shard_batch_plan(sizes, rank, world_size)
     else:
         plan = [(w, 0, n) for w, n in enumerate(sizes)]
@@ -400,7 +404,7 @@ def main():
                             % (wl_names[args.workload], len(worlds), n_agents, Nts[0], Nts[-1],
                                int(sum(int(w.plane_off[-1]) for w in worlds)), guesses),
                 "workload_key": args.workload,
-                "worlds_total": len(jobs), "agents_total": int(sum(sizes)) * (1 if (strong or world_size == 1) else world_size),
+                "worlds_total": len(jobs), "agents_total": int(sum(sizes)),
                 "agents_rank0": n_agents,
                 "admm_iterations_per_step_rank0": iters_step,
                 "sqp_iterations_rank0": int(sum(int(s.sqp_iters.sum()) for s in sols)),
@@ -410,8 +414,10 @@ def main():
                                          "admm_iterations": int(iters_agent[group_of == i].sum())}
                                         for i, g in enumerate(groups)],
                 "parallelism": ("1 GPU" if world_size == 1 else
-                                ("agents sharded in contiguous blocks over %d ranks" % world_size if strong else
-                                 "one whole differently-seeded copy per rank, %d ranks" % world_size)),
+                                ("one copy of the workload, agents sharded in contiguous blocks over %d ranks" % world_size
+                                 if strong else
+                                 "%d copies of the workload, agents sharded in contiguous blocks over %d ranks"
+                                 % (copies, world_size))),
                 "collective": "all_gather(final trajectories, device pointers) per step" if world_size > 1 else "none",
                 "per_rank": per_rank,
             },

@@ -98,7 +98,7 @@ def _newest_pmc(workload, step_ms):
             continue
         if d.get("workload", "map100") != workload:
             continue
-        ref_ms = d.get("ms_per_step")
+        ref_ms = d.get("ms_per_step")      # span of all agent-kernel dispatches of a step in the profiled run
         if ref_ms and abs(ref_ms - step_ms) > 0.2 * step_ms:
             return None, None, None, os.path.basename(path) + " (stale: %.1f ms per step there)" % ref_ms
         return (d.get("hbm_bytes_per_launch_dominant_kernel"), d.get("hbm_counter_frac_of_peak"),

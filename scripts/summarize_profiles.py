@@ -37,6 +37,32 @@ for f in find("trace/**/*kernel_stats.csv"):
         summary["dominant_kernel_avg_ms"] = float(dom["AverageNs"]) * 1e-6
         summary["ms_per_step"] = sum(float(r["TotalDurationNs"]) for r in agent) * 1e-6 / STEPS if len(agent) == 1 else \
             float(dom["AverageNs"]) * 1e-6
+# A launch group may be two dispatches of the kernel on one queue (its CU share first, the rest when CUs are released): the
+# group's time per step is the span from its first start to its last end, which is what bench.py's HIP events measure.
+for f in find("trace/**/*kernel_trace.csv"):
+    with open(f) as fh:
+        disp = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(fh)
+                if "dsqp_agent_kernel" in r.get("Kernel_Name", "")]
+    if disp and summary.get("dominant_kernel"):
+        disp.sort(key=lambda d: d[1])
+        t0 = disp[0][1]
+        steps, cur_end = [], None      # a step = dispatches of any agent kernel that overlap in time
+        for name, a, b in disp:
+            if cur_end is None or a > cur_end:
+                steps.append([])
+                cur_end = b
+            steps[-1].append((name, a, b))
+            cur_end = max(cur_end, b)
+        dom_spans = []
+        for st in steps:
+            d = [(a, b) for name, a, b in st if name == summary["dominant_kernel"]]
+            if d:
+                dom_spans.append((max(b for _, b in d) - min(a for a, _ in d)) * 1e-6)
+        step_spans = [(max(b for _, _, b in st) - min(a for _, a, _ in st)) * 1e-6 for st in steps]
+        if dom_spans:
+            summary["dominant_kernel_span_ms_per_step"] = sum(dom_spans) / len(dom_spans)
+            summary["ms_per_step"] = sum(step_spans) / len(step_spans)
+            summary["steps_in_trace"] = len(steps)
 pmc = {}
 for sub in ("fetch", "write", "sq"):
     for f in find("%s/**/*counter_collection.csv" % sub):

@@ -1349,14 +1349,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         double r6[6];
         CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0; });
         double kin[4] = {0, 0, 0, 0};
-        CSDO_FOR(i, NROW, {
-          if (S.act & (1u << i)) {
-            const double g = fma(rho_row<i>(S, rho, rho_eq), S.z[i], -S.y[i]);
-            CSDO_FOR(s_, 3, {
-              if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(S.c[i][s_], g, r6[row_col(i, s_)]);
-            });
-            if constexpr (i < 4) kin[i] = S.cn[i] * g;
-          }
+        CSDO_FOR(i, NROW, {   // every row, also those that do not exist at this t: their c, cn, y, z are zero (see the update)
+          const double g = fma(rho_row<i>(S, rho, rho_eq), S.z[i], -S.y[i]);
+          CSDO_FOR(s_, 3, {
+            if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(S.c[i][s_], g, r6[row_col(i, s_)]);
+          });
+          if constexpr (i < 4) kin[i] = S.cn[i] * g;
         });
         CSDO_FOR(j, 6, { SH(rhs, j, t) = r6[j]; });
         CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
@@ -1474,8 +1472,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             if (j < S.ncols) S.x[j] = alpha * xt[j] + (1.0 - alpha) * S.x[j];
             r6[j] = (j < S.ncols) ? sigma * S.x[j] : 0.0;
           });
+          // No test for rows that do not exist at this t (kinematic and control rows at the last timestep, start / goal rows in
+          // the interior): their coefficients, bounds, duals and slacks are all zero (assemble_home_rows, warm start) and stay
+          // zero through the formulas below, and straight-line code lets the rows' dependent chains overlap (16 basic blocks
+          // with an exec-mask test each could not).
           CSDO_FOR(i, NROW, {
-            if (S.act & (1u << i)) {
+            {
               double zt = 0.0;
               CSDO_FOR(s_, 3, {
                 if constexpr (row_col(i, s_) >= 0) zt = fma(S.c[i][s_], xt[row_col(i, s_)], zt);

@@ -1305,7 +1305,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if constexpr (UPDATE) {
             const double ztr = (ca[q] * xt[0] + cb[q] * xt[1]) + cy[q] * xt[2];
             const double zr = alpha * ztr + (1.0 - alpha) * zq;
-            const double zn = osqp_min(zr + rinv * yq, uu[q]);  // lower bound is -inf
+            const double zn = hot_min(zr + rinv * yq, uu[q]);  // lower bound is -inf
             const double d = rho_now * (zr - zn);
             if constexpr (KEEP) ROW(4 * p + q, R_DY) = d;
             yq = yq + d;
@@ -1497,7 +1497,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
                 hi_i = (MODE == 3) ? bnd[i + 6] : SH(lohi, i + 6, t);
                 lo_i = -hi_i;
               }
-              const double zn = osqp_min(osqp_max(zr + rinv * S.y[i], lo_i), hi_i);
+              const double zn = hot_min(hot_max(zr + rinv * S.y[i], lo_i), hi_i);
               const double d = rh * (zr - zn);
               if constexpr (keep_dy) WS(C_DY + i, t) = d;
               S.y[i] += d;

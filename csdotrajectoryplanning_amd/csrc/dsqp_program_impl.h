@@ -750,8 +750,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       unsigned eq = 0, loose = 0;
-      CSDO_FOR(i, NROW, {
-        if (S.act & (1u << i)) {
+      CSDO_FOR(i, NROW, {   // (every row: E = 1 and zero bounds where the row does not exist; classes only for those that do)
+        {
           const double Ei = CD(C_E + i, t);
           S.lo[i] = Ei * S.lo[i];
           S.hi[i] = Ei * S.hi[i];
@@ -759,6 +759,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           else if (S.hi[i] - S.lo[i] < RHO_TOL) eq |= 1u << i;
         }
       });
+      eq &= S.act;
+      loose &= S.act;
       S.eqmask = eq;
       S.loosemask = loose;
       WS(W_ACT, t) = (double)S.act;
@@ -1174,8 +1176,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           pvn_left = SH(carry, 5, t - 1);
         }
         double p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        CSDO_FOR(i, NROW, {
-          if (act_ & (1u << i)) {
+        (void)act_;
+        CSDO_FOR(i, NROW, {   // (every row: the ones that do not exist at this t are all-zero with E = 1 and change no maximum)
+          {
             double ci[3] = {0, 0, 0};
             CSDO_FOR(s, 3, {
               if constexpr (row_col(i, s) >= 0) ci[s] = WS(W_C + 3 * i + s, t);

@@ -19,6 +19,13 @@ namespace csdo {
 #define SINV(k, t) (MODE >= 1 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 #define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 #define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
+// mode 0, between ADMM blocks: y (0..15), z (16..31), x (32..37) of the iterate a block has just finished, field-major in the
+// idle LDS arrays behind the six doubles per lane that the residual update's exchange (carry2) uses
+#define HX(f, t) (sh.lohi + (size_t)(6 + (f)) * (size_t)sh.stride)[(unsigned)(t)]
+// the iterate as the residual update right behind a block reads it
+#define ITER_Y(i, t) ((MODE == 0) ? HX(i, t) : WS(W_Yv + (i), t))
+#define ITER_Z(i, t) ((MODE == 0) ? HX(NROW + (i), t) : WS(W_Zv + (i), t))
+#define ITER_X(j, t) ((MODE == 0) ? HX(2 * NROW + (j), t) : WS(W_X + (j), t))
 
 // ---------------------------------------------------------------------------------------------------------
 // Assembly of the home rows of timestep t at the linearisation point S.sol0 (unscaled values).
@@ -1144,11 +1151,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_PHASE(10);
       CSDO_LANES(t) {
         const unsigned act_ = (unsigned)WS(W_ACT, t);
-        CSDO_FOR(k, 5, { SH(carry2, k, t) = WS(W_X + k, t); });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = ITER_X(k, t); });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
         CSDO_FOR(k, 4, {                                          // to t+1: A'y share of the kinematic rows
-          SH(carry, k, t) = (act_ & (1u << k)) ? WS(W_CN + k, t) * WS(W_Yv + k, t) : 0.0;
+          SH(carry, k, t) = (act_ & (1u << k)) ? WS(W_CN + k, t) * ITER_Y(k, t) : 0.0;
         });
-        SH(carry, 4, t) = WS(W_X + 4, t);
+        SH(carry, 4, t) = ITER_X(4, t);
         SH(carry, 5, t) = WS(W_P + 2, t);
       }
       CSDO_SYNC();
@@ -1158,7 +1165,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const unsigned act_ = (unsigned)WS(W_ACT, t);
         const int ncols_ = (t < Nm) ? 6 : 4;
         double x_[6];
-        CSDO_FOR(j, 6, { x_[j] = WS(W_X + j, t); });
+        CSDO_FOR(j, 6, { x_[j] = ITER_X(j, t); });
         double einv[NROW], dinv[6];
         CSDO_FOR(i, NROW, { einv[i] = WS(C_E + i, t); });
         CSDO_FOR(j, 6, { dinv[j] = WS(C_D + j, t); });
@@ -1188,7 +1195,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               if constexpr (row_col(i, s) >= 0) ax = fma(ci[s], x_[row_col(i, s)], ax);
             });
             if constexpr (i < 4) ax = fma(WS(W_CN + i, t), xn[i], ax);
-            const double zi = WS(W_Zv + i, t), yi = WS(W_Yv + i, t);
+            const double zi = ITER_Z(i, t), yi = ITER_Y(i, t);
             const double ei = 1.0 / einv[i];
             const double res = ax - zi;
             p[0] = dmax(p[0], fabs(ei * res));
@@ -1526,6 +1533,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_PHASE(12);
       CSDO_LANES(t) {  // write the iterate back: nothing else changes inside a block
         LaneState& S = CSDO_LS(t);
+        if constexpr (MODE == 0) {
+          // ... and hand it to the residual update through LDS as well (the block's arrays are dead now): a workspace load
+          // queued behind these workspace stores waits until they are acknowledged
+          CSDO_FOR(i, NROW, {
+            HX(i, t) = S.y[i];
+            HX(NROW + i, t) = S.z[i];
+          });
+          CSDO_FOR(j, 6, { HX(2 * NROW + j, t) = S.x[j]; });
+        }
         CSDO_FOR(i, NROW, {
           WS(W_Yv + i, t) = S.y[i];
           WS(W_Zv + i, t) = S.z[i];

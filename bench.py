@@ -15,7 +15,7 @@ its block overlaps, solves its block, and the step ends with the path's only col
 trajectories on the device pointer.
 --scaling weak        (default) the job is N copies of the workload (the stand-in worlds of copy c seeded with 60 c): the
                       per-GPU work is fixed as N grows
---scaling strong      the job is ONE copy of the workload whatever N: bounded by its longest agent (47 ms against 88 ms / N)
+--scaling strong      the job is ONE copy of the workload whatever N: bounded by its longest agent (45 ms against 83 ms / N)
 Rank 0 prints ONE JSON line.
 
 metric  = agent-QP-iterations/sec: ADMM iterations executed by all agents of all ranks / wall time of the K steps (max

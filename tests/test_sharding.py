@@ -90,3 +90,28 @@ def test_two_rank_batch_shard_and_flat_gather(tmp_path, emu, veh_parm):
     assert [int(np.load(os.path.join(str(tmp_path), f"counts_{r}.npy"))[0]) for r in range(2)] == [4, 3]
     for r in range(2):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), f"flat_{r}.npy")), ref)
+
+
+def test_weak_scaling_job_gives_every_rank_one_copy():
+    """bench.py --scaling weak: the job is N copies of the workload, sharded like any other job; with equal copies the
+    contiguous blocks are the copies themselves, so the per-GPU work is the single-GPU work."""
+    from csdotrajectoryplanning_amd import sharding, workloads
+    n_ranks = 4
+    jobs = []
+    for c in range(n_ranks):
+        jobs += workloads.workload_jobs("map50", None, seed_offset=60 * c)
+    sizes = [workloads.job_agents(j) for j in jobs]
+    assert sum(sizes) == n_ranks * 1500
+    for r in range(n_ranks):
+        plan = sharding.shard_batch_plan(sizes, r, n_ranks)
+        assert [w for w, _, _ in plan] == list(range(60 * r, 60 * (r + 1)))
+        assert all(lo == 0 and hi == sizes[w] for w, lo, hi in plan)
+        assert all(jobs[w][2] == 60 * r for w, _, _ in plan)      # copy r: its stand-in worlds are seeded with 60 r
+    # strong scaling of one copy: blocks cut through worlds, every agent exactly once
+    sizes1 = sizes[:60]
+    seen = 0
+    for r in range(8):
+        for w, lo, hi in sharding.shard_batch_plan(sizes1, r, 8):
+            assert 0 <= lo < hi <= sizes1[w]
+            seen += hi - lo
+    assert seen == 1500

@@ -38,12 +38,14 @@ def _with_max_iter(world, k):
     return World(world.x0_bar, world.plane_off, world.planes, world.dimx, world.dimy, world.obstacles, world.veh, p)
 
 
-def _set(name):
+def _set(name, front="auto"):
     """All worlds of a BASELINE workload, built once per session by a spawn pool (the GPU is already initialised)."""
-    if name not in _CACHE:
+    key = (name, front)
+    if key not in _CACHE:
         from csdotrajectoryplanning_amd import workloads
-        _CACHE[name] = [w for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(name), min(THREADS, 32))]
-    return _CACHE[name]
+        _CACHE[key] = [w for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(name, front=front),
+                                                                   min(THREADS, 32))]
+    return _CACHE[key]
 
 
 def _per_agent(got, ref):
@@ -54,9 +56,12 @@ def _per_agent(got, ref):
     return d, dc, same
 
 
+@pytest.mark.parametrize("front", ["auto", "stand-in"])
 @pytest.mark.parametrize("workload", ["map100", "map50"])
-def test_first_qp_every_agent(gpu_handle, oracle, workload):
-    worlds = [_with_max_iter(w, 1) for w in _set(workload)]
+def test_first_qp_every_agent(gpu_handle, oracle, workload, front):
+    """front = auto: the measured workloads (front-end paths); stand-in: the round-1 worlds (longer horizons, up to 800 planes
+    per agent, initial guesses that violate their planes): other residency decisions, harder QPs."""
+    worlds = [_with_max_iter(w, 1) for w in _set(workload, front)]
     got = gpu_handle.solve_batch(worlds)
     ref = oracle.solve_batch(worlds, THREADS)
     d, dc, same = _per_agent(got, ref)

@@ -10,7 +10,8 @@
 //                                     reversing / change-of-direction penalties, closed list on the (t, yaw, y, x) grid,
 //                                     heuristic max(Reeds-Shepp, Euclid, 2-D obstacle-aware map) truncated to int as the
 //                                     reference's `int admissibleHeuristic` does, and the Reeds-Shepp "shot" towards the goal
-//                                     tried on every pop with the reference's rand()-gated range test (srand(0), csdo.cc:93)
+//                                     tried on every pop with the reference's random range test (rand() % 10 + 1 after
+//                                     srand(0), csdo.cc:93; here a generator owned by the call, so that the entry is re-entrant)
 //   common/motion_planning.h:140-199  rectangle SAT between vehicles (float), inflated-obstacle test in the vehicle frame
 // Exact path equality with the reference is not attainable (heap tie-breaking, OMPL internals, unordered_set order) and
 // not claimed; the tests check what PBS itself validates: every step is a motion primitive, no two rectangles overlap at
@@ -148,8 +149,14 @@ class LowLevel {
   }
 
   long expanded = 0;
+  uint64_t* rng_state = nullptr;   // one generator per csdo_front_end_plan call, shared by its low-level searches
 
  private:
+  uint32_t next_random() {          // 64-bit LCG (Knuth's MMIX constants), high bits
+    uint64_t& s = *rng_state;
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(s >> 33);
+  }
   struct Node {
     Pose s;
     int action;
@@ -277,7 +284,7 @@ class LowLevel {
   // Environment::isSolution: with probability growing towards the goal, try to finish with the Reeds-Shepp curve
   bool try_shot(int node_id, std::vector<std::pair<Pose, int>>& tail) {
     const Pose& s = nodes_[node_id].s;
-    const int random = std::rand() % 10 + 1;
+    const int random = (int)(next_random() % 10u) + 1;
     const float dx = (float)(std::fabs(s.x - goal_.x) / random), dy = (float)(std::fabs(s.y - goal_.y) / random);
     if (!((dx * dx) + (dy * dy) < 100.0)) return false;
     const rs::Path p = rs::shortest(s.x, s.y, s.yaw, goal_.x, goal_.y, goal_.yaw, C.r);
@@ -430,8 +437,12 @@ class Pbs {
   Pbs(const Consts& c, double dimx, double dimy, const std::vector<double>& obstacles, const std::vector<Pose>& starts,
       const std::vector<Pose>& goals)
       : C(c), starts_(starts), goals_(goals), n_((int)starts.size()) {
-    for (int a = 0; a < n_; ++a) engines_.emplace_back(new LowLevel(C, dimx, dimy, obstacles, goals_, a));
+    for (int a = 0; a < n_; ++a) {
+      engines_.emplace_back(new LowLevel(C, dimx, dimy, obstacles, goals_, a));
+      engines_.back()->rng_state = &rng_;
+    }
   }
+  void seed(uint64_t s) { rng_ = s; }
   ~Pbs() {
     for (HlNode* n : all_) delete n;
     for (LowLevel* e : engines_) delete e;
@@ -634,6 +645,7 @@ class Pbs {
   std::vector<HlNode*> stack_, all_;
   HlNode* goal_ = nullptr;
   clk::time_point deadline_;
+  uint64_t rng_ = 0;
 };
 
 }  // namespace
@@ -649,9 +661,9 @@ int front_end_plan(const double* starts, const double* goals, int Na, double dim
     S.emplace_back(starts[3 * a], starts[3 * a + 1], starts[3 * a + 2], 0, C);
     G.emplace_back(goals[3 * a], goals[3 * a + 1], goals[3 * a + 2], 0, C);
   }
-  std::srand(parm->rand_seed);   // csdo.cc:93: srand(0) before the search; the shot's range test draws from rand()
   const auto t0 = clk::now();
   Pbs pbs(C, dimx, dimy, obs, S, G);
+  pbs.seed(parm->rand_seed);     // csdo.cc:93 seeds the C library's generator with 0 before the search
   const bool ok = pbs.solve(parm->time_limit_s > 0 ? parm->time_limit_s : 20.0, parm->node_limit > 0 ? parm->node_limit : 1000000);
   out->seconds = std::chrono::duration<double>(clk::now() - t0).count();
   out->hl_expanded = (int32_t)pbs.hl_expanded;

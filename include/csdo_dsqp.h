@@ -192,7 +192,7 @@ typedef struct csdo_front_end_parm {
   double max_closed_set_size;                               /* per low-level search; 1e5 (environment.h:455-458) */
   double time_limit_s;                                      /* csdo.cc:100: 20 */
   int32_t node_limit;                                       /* high-level nodes; 0 = unlimited */
-  uint32_t rand_seed;                                       /* csdo.cc:93: srand(0) */
+  uint32_t rand_seed;                                       /* csdo.cc:93: srand(0); seeds a generator owned by the call */
 } csdo_front_end_parm;
 typedef struct csdo_paths {
   int32_t Na, status;

@@ -29,9 +29,12 @@ def run(name):
     parm = front_end.default_parm()
     parm.time_limit_s = TIME_LIMIT_S
     cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, parm)
+    out = os.path.join(OUT, name.replace(".yaml", ".npz"))
     if cp is None:
+        if os.path.exists(out):
+            os.remove(out)      # solved by an earlier version of the search
         return name, None
-    np.savez_compressed(os.path.join(OUT, name.replace(".yaml", ".npz")), states=cp.states, actions=cp.actions,
+    np.savez_compressed(out, states=cp.states, actions=cp.actions,
                         path_off=cp.path_off, hl_expanded=cp.hl_expanded, ll_expanded=cp.ll_expanded)
     return name, (cp.seconds, cp.hl_expanded, cp.ll_expanded)
 

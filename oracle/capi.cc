@@ -292,4 +292,48 @@ int csdo_oracle_osqp(int32_t n, int32_t m, const int32_t* P_p, const int32_t* P_
   return CSDO_OK;
 }
 
+// The same solve with the history the termination checks saw: hist[3 * k .. 3 * k + 2] = (rho, pri_res, dua_res) at check k
+// (every check_termination iterations); n_hist receives the number of checks (at most cap are written).  For the independent
+// cross-check of the iterate PATH (tests/test_oracle_admm_path.py): iteration count, status and rho history.
+int csdo_oracle_osqp_hist(int32_t n, int32_t m, const int32_t* P_p, const int32_t* P_i, const double* P_x,
+                          const double* q, const int32_t* A_p, const int32_t* A_i, const double* A_x, const double* l,
+                          const double* u, const double* x_warm, int32_t max_iter, int32_t adaptive_rho_interval,
+                          double eps_abs, double eps_rel, double* x_out, double* y_out, int32_t* info, int32_t cap,
+                          double* hist, int32_t* n_hist) {
+  Csc P, A;
+  P.m = P.n = n;
+  P.p.assign(P_p, P_p + n + 1);
+  P.i.assign(P_i, P_i + P.p[n]);
+  P.x.assign(P_x, P_x + P.p[n]);
+  A.m = m;
+  A.n = n;
+  A.p.assign(A_p, A_p + n + 1);
+  A.i.assign(A_i, A_i + A.p[n]);
+  A.x.assign(A_x, A_x + A.p[n]);
+  Settings st;
+  st.max_iter = max_iter;
+  st.adaptive_rho_interval = adaptive_rho_interval;
+  st.eps_abs = eps_abs;
+  st.eps_rel = eps_rel;
+  std::vector<double> xs, ys;
+  Trace tr;
+  const Info inf = osqp_solve_restated(P, std::vector<double>(q, q + n), A, std::vector<double>(l, l + m),
+                                       std::vector<double>(u, u + m), std::vector<double>(x_warm, x_warm + n), st,
+                                       xs, &ys, &tr);
+  std::copy(xs.begin(), xs.end(), x_out);
+  if (y_out) std::copy(ys.begin(), ys.end(), y_out);
+  info[0] = inf.status;
+  info[1] = inf.iter;
+  info[2] = inf.rho_updates;
+  info[3] = (int32_t)last_factor_nnz();
+  const int k = (int)tr.rho_hist.size();
+  *n_hist = k;
+  for (int e = 0; e < k && e < cap; ++e) {
+    hist[3 * e] = tr.rho_hist[e];
+    hist[3 * e + 1] = tr.pri_res_hist[e];
+    hist[3 * e + 2] = tr.dua_res_hist[e];
+  }
+  return CSDO_OK;
+}
+
 }  // extern "C"

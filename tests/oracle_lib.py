@@ -138,3 +138,30 @@ def osqp(P_triu, q, A, l, u, x_warm, max_iter=4000, adaptive_rho_interval=25, ep
       abi.as_int32_p(Ai), abi.as_double_p(Ax), abi.as_double_p(l), abi.as_double_p(u), abi.as_double_p(xw), max_iter,
       adaptive_rho_interval, eps_abs, eps_rel, abi.as_double_p(x), abi.as_double_p(y), abi.as_int32_p(info))
     return x, y, dict(status=int(info[0]), iter=int(info[1]), rho_updates=int(info[2]), factor_nnz=int(info[3]))
+
+
+def osqp_hist(P_triu, q, A, l, u, x_warm, max_iter=400, adaptive_rho_interval=25, eps_abs=1e-3, eps_rel=1e-3):
+    """oracle.osqp plus what every termination check saw: returns (x, y, info, hist[k] = (rho, pri_res, dua_res))."""
+    import scipy.sparse as sp
+    P = sp.csc_matrix(P_triu)
+    A = sp.csc_matrix(A)
+    P.sort_indices()
+    A.sort_indices()
+    n, m = P.shape[0], A.shape[0]
+    f = lib().csdo_oracle_osqp_hist
+    f.argtypes = [C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p, abi.c_int32_p,
+                  abi.c_int32_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_int32, C.c_int32,
+                  C.c_double, C.c_double, abi.c_double_p, abi.c_double_p, abi.c_int32_p, C.c_int32, abi.c_double_p,
+                  abi.c_int32_p]
+    x, y, info = np.zeros(n), np.zeros(m), np.zeros(4, np.int32)
+    cap = max_iter // 25 + 2
+    hist, nh = np.zeros((cap, 3)), np.zeros(1, np.int32)
+    arr = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    Pp, Pi, Px = arr(P.indptr, np.int32), arr(P.indices, np.int32), arr(P.data, np.float64)
+    Ap, Ai, Ax = arr(A.indptr, np.int32), arr(A.indices, np.int32), arr(A.data, np.float64)
+    q, l, u, xw = (arr(v, np.float64) for v in (q, l, u, x_warm))
+    f(n, m, abi.as_int32_p(Pp), abi.as_int32_p(Pi), abi.as_double_p(Px), abi.as_double_p(q), abi.as_int32_p(Ap),
+      abi.as_int32_p(Ai), abi.as_double_p(Ax), abi.as_double_p(l), abi.as_double_p(u), abi.as_double_p(xw), max_iter,
+      adaptive_rho_interval, eps_abs, eps_rel, abi.as_double_p(x), abi.as_double_p(y), abi.as_int32_p(info), cap,
+      abi.as_double_p(hist), abi.as_int32_p(nh))
+    return x, y, dict(status=int(info[0]), iter=int(info[1]), rho_updates=int(info[2])), hist[:min(int(nh[0]), cap)]

@@ -61,8 +61,8 @@ def main():
             "same_counts": int(same.sum()), "max_d": float(d.max()), "median_d": float(np.median(d)),
             "n_gt_1e-6": int((d > 1e-6).sum()), "n_gt_1e-5": int((d > 1e-5).sum()), "n_gt_1e-4": int((d > 1e-4).sum()),
             "n_gt_1e-3": int((d > 1e-3).sum()), "n_gt_2e-2": int((d > 2e-2).sum()),
-            "n_corridor_differs": int((dc > 0).sum()),
-            "n_gt_1e-4_with_same_corridor": int(((d > 1e-4) & (dc == 0)).sum()),
+            "n_box_step_flipped": int((dc > 0.05).sum()),          # a box edge moved by a 0.1 m growth step
+            "n_gt_1e-4_without_box_flip": int(((d > 1e-4) & (dc < 0.05)).sum()),
             "listed": sorted(rows, key=lambda r: -r["d"])[:40]}
     s = json.dumps(report, indent=1)
     print(s)

@@ -35,6 +35,29 @@ def lib():
     return _LIB
 
 
+_FMA = None
+
+
+def solve_batch_fma(worlds, n_threads=1):
+    """The same oracle source built with fused multiply-adds (oracle/Makefile: libcsdo_oracle_fma.so): how sensitive the
+    reference algorithm itself is to rounding.  Never a parity target."""
+    global _FMA
+    if _FMA is None:
+        path = os.path.join(_ROOT, "oracle", "libcsdo_oracle_fma.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "libcsdo_oracle_fma.so"], check=True)
+        _FMA = C.CDLL(path)
+        _FMA.csdo_oracle_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
+    sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
+    probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
+    res = (abi.Result * len(worlds))(*[s._c for s in sols])
+    assert _FMA.csdo_oracle_solve_batch(probs, len(worlds), res, n_threads) == 0
+    for s, r in zip(sols, res):
+        s._c = r
+        s.finish()
+    return sols
+
+
 def solve(world: World, n_threads=1) -> Solution:
     sol = Solution.allocate(world.Na, world.Nt)
     p = world.c_problem()

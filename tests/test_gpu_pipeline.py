@@ -56,7 +56,12 @@ def test_pipeline_end_to_end(gpu_handle, oracle):
     d, dc, same = _per_agent(got, ref)
     print("pipeline worlds: identical counts %.3f, <= 1e-6 %.3f, <= 1e-4 %.3f, max %.2e" %
           (same.mean(), (d <= 1e-6).mean(), (d <= 1e-4).mean(), d.max()))
-    assert same.mean() >= 0.97 and (d <= 1e-4).mean() >= 0.90 and np.median(d) <= 1e-6
+    # 160 agents (measured: identical counts on all, 2 beyond 1e-4): whoever is beyond 1e-4 must be an agent the oracle itself
+    # is rounding-sensitive on (its FMA build differs from it by more than 1e-6 there)
+    d_sens = _per_agent(oracle.solve_batch_fma(worlds, 8), ref)[0]
+    bad = [(int(a), float(d[a]), float(d_sens[a])) for a in np.nonzero(~same | (d > 1e-4))[0] if not d_sens[a] > 1e-6]
+    assert not bad, bad
+    assert same.mean() >= 0.99 and (d <= 1e-4).mean() >= 0.975 and np.median(d) <= 1e-7 and d.max() <= 1.0
     for (w, inst), g, r in zip(items, got, ref):
         assert g.solver_status == r.solver_status or {g.solver_status, r.solver_status} <= {1, 2}
         # the device validator on the device result: what the authors check after the fact (collision_detection.py)

@@ -11,9 +11,10 @@ What is pinned per agent (not per cent):
     variables, re-linearised up to ten times, amplifies a last-bit difference by ~30x per SQP iteration (measured, DESIGN
     section 4): the oracle differs from ITSELF under a change of rounding by the same amounts, and so does the HIP build
     from the lane-serial host build of its own source (libm ulps).  So the chain is pinned (a) against that lane-serial
-    build and (b) against the oracle by per-workload fractions set just above the measurements, every agent with
-    different counts or beyond 2e-2 listed, and (c) by an implementation-independent acceptance of the final trajectories
-    (feasibility residuals, objective, obstacle validator: both solvers must agree).
+    build, (b) against the oracle by bars fitted to the measurements with every agent beyond 1e-4 held against a committed
+    outlier list (tests/golden/chain_outliers_*.json) and against the oracle's own rounding sensitivity on that agent,
+    (c) by a growth-law test on every listed outlier (max_iter = 1..10) and (d) by an implementation-independent
+    acceptance of the final trajectories (feasibility residuals, objective, obstacle validator: both solvers must agree).
 """
 import os
 
@@ -89,15 +90,34 @@ def test_second_qp_with_flips_listed(gpu_handle, oracle, workload):
     assert np.mean(d <= 1e-6) >= 0.98, float(np.mean(d <= 1e-6))
 
 
-# Measured on MI355X (profiles/r02_parity_*.json): over a chain of up to ten QPs a last-bit difference grows by ~30x per SQP
-# iteration for the sensitive agents - the HIP build and the lane-serial host build of the SAME source (they differ only
-# in libm ulps of sin/cos/tan) already disagree by more than 1e-4 on 3.8 % of the map100 agents (horizons 142-226, up to
-# ten QPs) and on 0.07 % of the map50 agents (horizons 64-103).  The chain bars are therefore fractions, per workload,
-# set just above what was measured; the per-QP tests above are the exact ones.
-CHAIN_BARS = {   # min fraction with identical counts, min fraction <= 1e-6, min fraction <= 1e-4, max median
-    "map100": dict(same=0.985, le_1e6=0.70, le_1e4=0.90, median=1e-6),
-    "map50": dict(same=0.995, le_1e6=0.95, le_1e4=0.99, median=1e-8),
+# Measured on MI355X (profiles/r03_chain_*.json, scripts/chain_parity.py): over a chain of up to ten QPs a last-bit difference
+# grows by a factor 3-9 per cut of the chain for the sensitive agents, with single steps of 10^2-10^6 where a QP's termination
+# check or a 0.1 m box growth step flips - and the ORACLE differs from ITSELF built with fused multiply-adds by the same
+# factors on the same agents (growth 3.3-9.2 per cut against 3.3-8.7 for HIP vs oracle, the same worst single steps).  So:
+#   * the bars below are fitted to the measured front-end workloads (map100: 2999/3000 identical counts, 2972 within 1e-4,
+#     max 0.49; map50: 1500/1500, 1497, max 4.5e-3);
+#   * every agent beyond 1e-4 must be LISTED in tests/golden/chain_outliers_<workload>.json (written by scripts/chain_parity.py
+#     on the GPU) or be an agent on which the oracle differs from its own FMA build by more than 1e-6 in this very run: a new
+#     outlier on an agent the reference algorithm is NOT sensitive on fails;
+#   * test_outlier_growth_* runs every listed outlier alone with max_iter = 1..10 on HIP, the lane-serial build, the oracle and
+#     the FMA oracle and asserts the growth law.
+CHAIN_BARS = {   # min fraction with identical counts, min fraction <= 1e-6, min fraction <= 1e-4, max median, max
+    "map100": dict(same=0.999, le_1e6=0.93, le_1e4=0.985, median=1e-7, max=1.0),
+    "map50": dict(same=0.999, le_1e6=0.98, le_1e4=0.997, median=1e-8, max=1.0),
 }
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fixture(workload):
+    import json
+    with open(os.path.join(GOLDEN, "chain_outliers_%s.json" % workload)) as f:
+        return json.load(f)
+
+
+def _world_agent(worlds, flat_index):
+    first = np.cumsum([0] + [w.Na for w in worlds])
+    wi = int(np.searchsorted(first, flat_index, side="right") - 1)
+    return wi, int(flat_index - first[wi])
 
 
 def _chain_check(d, same, workload, what):
@@ -107,19 +127,36 @@ def _chain_check(d, same, workload, what):
     print(what, workload, stats)
     assert stats["same"] >= bars["same"] and stats["le_1e6"] >= bars["le_1e6"] and stats["le_1e4"] >= bars["le_1e4"], stats
     assert stats["median"] <= bars["median"], stats
-    assert stats["max"] <= 4.5, stats            # both stay inside the +-2 m trust region around x0_bar + tolerance
+    assert stats["max"] <= bars["max"], stats      # (both stay inside the +-2 m trust region around x0_bar)
+
+
+def _outliers_are_accounted_for(worlds, d, same, d_ref_sens, workload, what):
+    """Every agent beyond 1e-4 (or with different counts) is in the committed list or is one the reference algorithm itself
+    is rounding-sensitive on (d_ref_sens: oracle vs its FMA build, this run); returns the outliers found."""
+    fx = _fixture(workload)
+    listed = {(o["world"], o["agent"]) for o in fx["outliers"]}
+    found = [_world_agent(worlds, g) for g in np.nonzero(~same | (d > parity.TOL))[0]]
+    new = [(wa, float(d[g])) for wa, g in zip(found, np.nonzero(~same | (d > parity.TOL))[0])
+           if wa not in listed and not d_ref_sens[g] > 1e-6]
+    print(what, workload, "outliers found:", found, "of them not in the committed list:", [wa for wa in found if wa not in listed])
+    assert not new, ("outliers on agents the reference algorithm is not sensitive on", new)
+    assert len(found) <= 1.25 * len(listed) + 2, (len(found), len(listed))
+    return found
 
 
 @pytest.mark.parametrize("workload", ["map100", "map50"])
-def test_full_chain_hip_build_against_lane_serial_build(gpu_handle, emu, workload):
+def test_full_chain_hip_build_against_lane_serial_build(gpu_handle, emu, oracle, workload):
     """Same program source as HIP device code and lane-serially on the host, every agent of the set."""
     worlds = _set(workload)
     got = gpu_handle.solve_batch(worlds)
     ref = emu.solve_batch(worlds, 0, THREADS)
     d, dc, same = _per_agent(got, ref)
-    listed = [(int(a), float(d[a]), float(dc[a])) for a in np.nonzero(~same | (d > parity.CORRIDOR_FLIP_TOL))[0]]
-    print("HIP vs lane-serial: agents with different counts or above 2e-2:", listed)
     _chain_check(d, same, workload, "HIP vs lane-serial build")
+    assert same.all()                                  # measured: identical counts on every agent of both sets
+    d_sens = _per_agent(oracle.solve_batch_fma(worlds, THREADS), oracle.solve_batch(worlds, THREADS))[0]
+    # the two builds differ in libm ulps only: whatever exceeds 1e-4 must be an agent the oracle is itself sensitive on
+    bad = [(_world_agent(worlds, g), float(d[g]), float(d_sens[g])) for g in np.nonzero(d > parity.TOL)[0] if not d_sens[g] > 1e-6]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("workload", ["map100", "map50"])
@@ -129,22 +166,63 @@ def test_full_chain_against_oracle_with_acceptance(gpu_handle, oracle, workload)
     got = gpu_handle.solve_batch(worlds)
     ref = oracle.solve_batch(worlds, THREADS)
     d, dc, same = _per_agent(got, ref)
-    listed = [(int(a), float(d[a]), float(dc[a])) for a in np.nonzero(~same | (d > parity.CORRIDOR_FLIP_TOL))[0]]
-    print("HIP vs oracle: agents with different counts or above 2e-2:", listed)
     _chain_check(d, same, workload, "HIP vs oracle")
+    d_sens = _per_agent(oracle.solve_batch_fma(worlds, THREADS), ref)[0]
+    _outliers_are_accounted_for(worlds, d, same, d_sens, workload, "HIP vs oracle")
     # implementation-independent acceptance: the reference's own feasibility test (isFeasible, dsqp_solver.cc:292-420)
-    # and the objective, evaluated in numpy on both results: the same agents pass, and the objective agrees
-    for w, g, r in zip(worlds, got, ref):
+    # and the objective, evaluated in numpy on both results.  Agents within 1e-4 of the oracle: the same verdict unless a
+    # residual sits within 1e-3 of its threshold, the same objective to 1e-3; the outliers: listed above.
+    first = np.cumsum([0] + [w.Na for w in worlds])
+    for k, (w, g, r) in enumerate(zip(worlds, got, ref)):
+        close = d[first[k]:first[k + 1]] <= parity.TOL
         fg, fr = results.feasibility(w, g.solutions), results.feasibility(w, r.solutions)
         ok_g = (fg["kin"] < 1e-2) & (fg["planes"] < 1e-1)
         ok_r = (fr["kin"] < 1e-2) & (fr["planes"] < 1e-1)
-        assert (ok_g == ok_r).mean() >= 0.96
-        both = (g.last_status == 1) & (r.last_status == 1)
-        np.testing.assert_allclose(fg["objective"][both], fr["objective"][both], rtol=0.05, atol=2e-2)
+        borderline = (np.abs(fr["kin"] - 1e-2) < 1e-3) | (np.abs(fr["planes"] - 1e-1) < 1e-3)
+        assert np.all((ok_g == ok_r) | borderline | ~close), (k, np.nonzero(ok_g != ok_r)[0])
+        both = (g.last_status == 1) & (r.last_status == 1) & close
+        np.testing.assert_allclose(fg["objective"][both], fr["objective"][both], rtol=1e-3, atol=1e-4)
         vg = results.validate(g.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
         vr = results.validate(r.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
         assert (vg.obstacle_collisions == 0) == (vr.obstacle_collisions == 0)
         assert g.initial_static_legal == r.initial_static_legal
+
+
+@pytest.mark.parametrize("workload", ["map100", "map50"])
+def test_outlier_growth_is_the_reference_algorithms_own_amplification(gpu_handle, emu, oracle, workload):
+    """Every committed outlier alone, the chain cut after k = 1..10 QPs (QpParm.max_iter = k), on HIP, the lane-serial build,
+    the oracle and the oracle built with fused multiply-adds.  With d_k = max |difference| after the cut at k:
+      * the seed is small: d_1(HIP, oracle) <= 1e-6 - one QP is where the kernel is compared, everything later is the chain;
+      * HIP-vs-oracle grows like the oracle's own rounding sensitivity: geometric-mean growth per cut within a factor 2 of
+        oracle-vs-FMA-oracle, worst single step within a factor 30 of its worst single step (no jump of HIP's own);
+      * at every k HIP is no further from the oracle than 300x, and from the lane-serial build of its own source than 100x,
+        what the oracle's two builds have differed by up to that k (floor 1e-9)."""
+    fx = _fixture(workload)
+    worlds = _set(workload)
+    singles = [worlds[o["world"]].subset(o["agent"], o["agent"] + 1) for o in fx["outliers"]]
+    assert singles, "no outliers listed"
+    D = {name: np.zeros((len(singles), 10)) for name in ("hip_oracle", "fma_oracle", "hip_emu")}
+    for k in range(1, 11):
+        ws = [_with_max_iter(w, k) for w in singles]
+        hip, ref = gpu_handle.solve_batch(ws), oracle.solve_batch(ws, THREADS)
+        fma, em = oracle.solve_batch_fma(ws, THREADS), emu.solve_batch(ws, 0, THREADS)
+        for j in range(len(ws)):
+            D["hip_oracle"][j, k - 1] = np.abs(hip[j].solutions - ref[j].solutions).max()
+            D["fma_oracle"][j, k - 1] = np.abs(fma[j].solutions - ref[j].solutions).max()
+            D["hip_emu"][j, k - 1] = np.abs(hip[j].solutions - em[j].solutions).max()
+    ho, fo, he = D["hip_oracle"], D["fma_oracle"], D["hip_emu"]
+    assert ho[:, 0].max() <= 1e-6, ho[:, 0]
+    growth = lambda a: (np.maximum(a[:, -1], 1e-10) / np.maximum(a[:, 0], 1e-10)) ** (1.0 / 9.0)
+    jump = lambda a: (np.maximum(a[:, 1:], 1e-10) / np.maximum(a[:, :-1], 1e-10)).max(axis=1)
+    g_h, g_f, j_h, j_f = growth(ho), growth(fo), jump(ho), jump(fo)
+    envelope = np.maximum.accumulate(np.maximum(fo, 1e-9), axis=1)
+    for j, o in enumerate(fx["outliers"]):
+        print("outlier world %d agent %d: growth per cut %.1f (oracle's own %.1f), worst step %.0f (%.0f), d_k = %s" %
+              (o["world"], o["agent"], g_h[j], g_f[j], j_h[j], j_f[j], " ".join("%.0e" % v for v in ho[j])))
+    assert np.all(g_h <= 2.0 * g_f), (g_h, g_f)
+    assert np.all(j_h <= 30.0 * j_f), (j_h, j_f)
+    assert np.all(ho <= 300.0 * envelope), float((ho / envelope).max())
+    assert np.all(he <= 100.0 * envelope), float((he / envelope).max())
 
 
 def test_synthetic_1024_batch(gpu_handle, oracle):
@@ -160,11 +238,16 @@ def test_synthetic_1024_batch(gpu_handle, oracle):
         alone = gpu_handle.solve(full[k])
         n = worlds[k].Na
         assert np.array_equal(alone.solutions[:n], got[k].solutions) and np.array_equal(alone.admm_iters[:n], got[k].admm_iters)
-    for k in (3, 20):
-        r = oracle.solve(worlds[k], THREADS)
-        c = parity.compare(r, got[k])
-        same = (r.sqp_iters == got[k].sqp_iters) & (r.admm_iters == got[k].admm_iters)
-        assert same.mean() >= 0.95 and np.median(c["d_sol"]) < 1e-6
+    # every world against the oracle: the first QP of all 1024 agents (identical counts, <= 1e-5), then the full chain with
+    # the map100 bars (these are the first 21 map100 worlds; their chain outliers are in that set's list)
+    first_qp = [_with_max_iter(w, 1) for w in worlds]
+    d1, _, same1 = _per_agent(gpu_handle.solve_batch(first_qp), oracle.solve_batch(first_qp, THREADS))
+    assert same1.all() and d1.max() <= FIRST_QP_TOL, (int((~same1).sum()), float(d1.max()))
+    ref = oracle.solve_batch(worlds, THREADS)
+    d, dc, same = _per_agent(got, ref)
+    _chain_check(d, same, "map100", "synth1024: HIP vs oracle")
+    d_sens = _per_agent(oracle.solve_batch_fma(worlds, THREADS), ref)[0]
+    _outliers_are_accounted_for(worlds, d, same, d_sens, "map100", "synth1024: HIP vs oracle")
     for w, g in zip(worlds, got):
         ok = g.last_status == 1
         assert np.all(g.solutions[:, -1, 4:] == 0)

@@ -55,6 +55,8 @@ def lib():
         L.csdo_preprocess_device.argtypes = [H] + L.csdo_preprocess.argtypes
         L.csdo_validate.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                     C.c_double, C.POINTER(abi.Vehicle), C.c_double, C.POINTER(abi.Validation)]
+        L.csdo_validate_frames.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32,
+                                           C.c_double, C.c_double, C.POINTER(abi.Vehicle), C.c_double, C.POINTER(abi.Validation)]
         L.csdo_bridge_free.argtypes = [C.POINTER(abi.BridgeOut)]
         L.csdo_bridge_free.restype = None
         L.csdo_generate_boxes.argtypes = [H, abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,

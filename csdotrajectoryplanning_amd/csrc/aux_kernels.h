@@ -18,4 +18,7 @@ hipError_t k0_emit(const K0Centres& c, int Na, int Nt, double reach, float lengt
 // out-of-map (t, agent) count, minimum clearance as an order-preserving key
 hipError_t validate_launch(const double* sol, int Na, int Nt, const double* obs, int n_obs, double half_shift, double hl,
                            double hw, double dimx, double dimy, int check_map, unsigned long long* out, hipStream_t s);
+// frames[Na][(Nt - 1) * S + 1][6] = the poses the authors' animation looks at with S frames per move (getState,
+// scripts/visualize.py:256-281: linear in x, y, yaw between states, the earlier yaw moved by 2 pi when they are more than pi apart)
+hipError_t expand_frames_launch(const double* sol, int Na, int Nt, int S, double* frames, hipStream_t s);
 }  // namespace csdo

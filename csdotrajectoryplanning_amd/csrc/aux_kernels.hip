@@ -214,7 +214,42 @@ __global__ void validate_obstacles_kernel(const double* __restrict__ sol, int Na
   }
 }
 
+// one lane per (agent, frame): getState of scripts/visualize.py:256-281, the same operations in the same order
+__global__ void expand_frames_kernel(const double* __restrict__ sol, int Na, int Nt, int S, double* __restrict__ frames) {
+  const int nf = (Nt - 1) * S + 1;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)Na * nf) return;
+  const int a = (int)(g / nf), f = (int)(g - (long long)a * nf);
+  const double t = (double)f / (double)S;
+  const int idx = (int)ceil(t);                       // first state whose time is >= t
+  double* o = frames + (size_t)g * 6;
+  const double* nx = sol + ((size_t)a * Nt + idx) * 6;
+  double px = nx[0], py = nx[1], pyaw = nx[2];
+  if (idx > 0) {
+    const double* ls = nx - 6;
+    double yaw_last = ls[2];
+    const double yaw_next = nx[2];
+    const double pi = 3.141592653589793;
+    if ((yaw_last - yaw_next) > pi) yaw_last = yaw_last - 2 * pi;
+    else if ((yaw_next - yaw_last) > pi) yaw_last = yaw_last + 2 * pi;
+    const double tau = (t - (double)(idx - 1)) / 1.0;
+    px = (nx[0] - ls[0]) * tau + ls[0];
+    py = (nx[1] - ls[1]) * tau + ls[1];
+    pyaw = (yaw_next - yaw_last) * tau + yaw_last;
+  }
+  o[0] = px;
+  o[1] = py;
+  o[2] = pyaw;
+  o[3] = o[4] = o[5] = 0.0;
+}
+
 }  // namespace
+
+hipError_t expand_frames_launch(const double* sol, int Na, int Nt, int S, double* frames, hipStream_t s) {
+  const long long n = (long long)Na * ((long long)(Nt - 1) * S + 1);
+  hipLaunchKernelGGL(expand_frames_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sol, Na, Nt, S, frames);
+  return hipGetLastError();
+}
 
 hipError_t k0_count(const K0Centres& c, int Na, int Nt, double reach, float length, float width, int* counts, int* collide,
                     long long* offsets, hipStream_t s) {

@@ -87,7 +87,7 @@ struct csdo_handle_s {
   double last_kernel_s = 0.0;
   DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d, queues;
   DevBuf box_pts, box_obs, box_out, box_status;
-  DevBuf k0_centres, k0_counts, k0_offsets, k0_pairs, k0_coef, k0_flag, val_sol, val_obs, val_out;
+  DevBuf k0_centres, k0_counts, k0_offsets, k0_pairs, k0_coef, k0_flag, val_sol, val_obs, val_out, val_frames;
   DevBuf prof;
   PinnedBuf stage_up, stage_down;   // page-locked staging of the packed inputs / outputs
   double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
@@ -210,7 +210,7 @@ void csdo_dsqp_destroy(csdo_handle h) {
   for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
                     &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->queues, &h->box_pts,
                     &h->box_obs, &h->box_out, &h->box_status, &h->prof, &h->k0_centres, &h->k0_counts, &h->k0_offsets,
-                    &h->k0_pairs, &h->k0_coef, &h->k0_flag, &h->val_sol, &h->val_obs, &h->val_out})
+                    &h->k0_pairs, &h->k0_coef, &h->k0_flag, &h->val_sol, &h->val_obs, &h->val_out, &h->val_frames})
     b->release();
   h->stage_up.release();
   h->stage_down.release();
@@ -598,10 +598,14 @@ int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* a
 
 // Independent geometric check of final trajectories on the device: vehicle rectangles against each other per timestep
 // (separating axes, touching counts) and against the obstacle discs, optional map bounds (dimx <= 0: skipped).
-int csdo_validate(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt, const double* obstacles, int32_t n_obs,
-                  double dimx, double dimy, const csdo_vehicle* veh, double margin, csdo_validation* out) {
-  if (!h || !solutions || !veh || !out || Na < 1 || Nt < 1 || n_obs < 0 || (n_obs > 0 && !obstacles)) return CSDO_EINVAL;
-  if (Na >= (1 << 20) || Nt >= (1 << 20) || n_obs >= (1 << 20)) return CSDO_ELIMIT;
+static int validate_impl(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt, int32_t frames_per_move,
+                         const double* obstacles, int32_t n_obs, double dimx, double dimy, const csdo_vehicle* veh, double margin,
+                         csdo_validation* out) {
+  if (!h || !solutions || !veh || !out || Na < 1 || Nt < 1 || n_obs < 0 || (n_obs > 0 && !obstacles) || frames_per_move < 0)
+    return CSDO_EINVAL;
+  // frames_per_move == 0: the Nt states as they are; S >= 1: the (Nt - 1) * S + 1 frames of the authors' animation
+  const long long n_frames = frames_per_move ? ((long long)(Nt - 1) * frames_per_move + 1) : Nt;
+  if (Na >= (1 << 20) || n_frames >= (1 << 20) || n_obs >= (1 << 20)) return CSDO_ELIMIT;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   int rc;
   const size_t b_sol = (size_t)Na * Nt * 6 * sizeof(double), b_obs = (size_t)n_obs * 3 * sizeof(double);
@@ -614,8 +618,15 @@ int csdo_validate(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt
   HIP_OK(hipMemcpyAsync(h->val_sol.p, solutions, b_sol, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
   if (n_obs) HIP_OK(hipMemcpyAsync(h->val_obs.p, obstacles, b_obs, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
   HIP_OK(hipMemcpyAsync(h->val_out.p, init, sizeof(init), hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  const double* poses = (const double*)h->val_sol.p;
+  if (frames_per_move) {
+    if ((rc = h->val_frames.ensure((size_t)Na * n_frames * 6 * sizeof(double))) != CSDO_OK) return rc;
+    if (expand_frames_launch((const double*)h->val_sol.p, Na, Nt, frames_per_move, (double*)h->val_frames.p, s) != hipSuccess)
+      return CSDO_EDEVICE;
+    poses = (const double*)h->val_frames.p;
+  }
   const double half_shift = 0.5 * (veh->LF - veh->LB), hl = 0.5 * (veh->LF + veh->LB) + margin, hw = 0.5 * veh->car_width + margin;
-  if (validate_launch((const double*)h->val_sol.p, Na, Nt, (const double*)h->val_obs.p, n_obs, half_shift, hl, hw, dimx, dimy,
+  if (validate_launch(poses, Na, (int)n_frames, (const double*)h->val_obs.p, n_obs, half_shift, hl, hw, dimx, dimy,
                       dimx > 0 && dimy > 0, (unsigned long long*)h->val_out.p, s) != hipSuccess)
     return CSDO_EDEVICE;
   HIP_OK(hipMemcpyAsync(res, h->val_out.p, sizeof(res), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
@@ -643,6 +654,20 @@ int csdo_validate(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt
     out->min_obstacle_clearance = d;
   }
   return CSDO_OK;
+}
+
+int csdo_validate(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt, const double* obstacles, int32_t n_obs,
+                  double dimx, double dimy, const csdo_vehicle* veh, double margin, csdo_validation* out) {
+  return validate_impl(h, solutions, Na, Nt, 0, obstacles, n_obs, dimx, dimy, veh, margin, out);
+}
+
+// The same check on the frames of the authors' animation: frames_per_move frames per move (framesPerMove of
+// scripts/visualize.py:27,186), poses between two states interpolated as getState does (:256-281).  Indices in `out` are frames.
+int csdo_validate_frames(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt, int32_t frames_per_move,
+                         const double* obstacles, int32_t n_obs, double dimx, double dimy, const csdo_vehicle* veh,
+                         double margin, csdo_validation* out) {
+  if (frames_per_move < 1) return CSDO_EINVAL;
+  return validate_impl(h, solutions, Na, Nt, frames_per_move, obstacles, n_obs, dimx, dimy, veh, margin, out);
 }
 
 void csdo_vehicle_default(csdo_vehicle* v) {

@@ -4,6 +4,11 @@ write_solutions   the reference's result YAML (dumpSolutions, sqp/inter_agent_co
                   order (scripts/analysis_result.py reads the header positionally), %.3f, steer / omega in "degrees" with
                   the reference's 180/3.14 factor, no v / omega on the last timestep.
 read_solutions    the inverse, for round-trip tests and for feeding the validator from a file.
+write_corridors   dumpCorridors (sqp/utils.cc:62-89): per agent and timestep the front and the rear disc centre (float-rounded, as
+                  State stores them) with its box, default ostream formatting; read_corridors is the inverse.
+write_guesses     the initial-guess dump of csdo.cc:138-140 (dumpSolutions on x0_bar); output_paths derives the three file
+                  names the way csdo.cc:76,139,164 does.
+interpolate_states  getState of scripts/visualize.py:256-281: what the authors' per-frame collision print looks at between states.
 validate          independent geometric check of final trajectories in the spirit of scripts/collision_detection.py:
                   vehicle rectangles against each other (separating axes) and against the circular obstacles, per
                   timestep.  Own formulation, vectorised numpy; not on the hot path.
@@ -44,6 +49,67 @@ def write_solutions(path, solutions, stats=None):
             out.append("      omega: %.3f" % (w * _DEG))
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
+
+
+def output_paths(output_file):
+    """(result, guesses, corridors) file names as csdo.cc:76,139,164 derives them: the output file must end in `.yaml`;
+    the prefix is everything but those five characters."""
+    output_file = str(output_file)
+    if not output_file.endswith(".yaml"):
+        raise ValueError("the output file must end with .yaml (csdo.cc:76 cuts five characters)")
+    prefix = output_file[:-5]
+    return output_file, prefix + "_guesses.yaml", prefix + "_corridors.yaml"
+
+
+def write_guesses(path, x0_bar, stats=None):
+    """csdo.cc:138-140 (--initial_guess): the interpolated initial guess in the result format, with the statistics gathered so
+    far (the reference passes the same SolutionStatistics object: search and preprocess times set, the rest at its defaults)."""
+    write_solutions(path, x0_bar, stats)
+
+
+def _g(v):
+    """A double through a default-constructed std::ofstream: %g with six significant digits."""
+    return "%g" % float(v)
+
+
+def write_corridors(path, corridors, x0_bar, veh):
+    """dumpCorridors, sqp/utils.cc:62-89.  corridors [Na][Nt][8] = xf_min, xf_max, yf_min, yf_max, xr_min, xr_max, yr_min, yr_max
+    (csdo_result.corridors); x0_bar [Na][Nt][>=3].  Two list items per timestep: [xf, yf, xf_min, xf_max, yf_min, yf_max] then
+    the same for the rear disc; the disc centres are State's float members (common/motion_planning.h:111-118)."""
+    cor = np.asarray(corridors, dtype=np.float64)
+    g = np.asarray(x0_bar, dtype=np.float64)
+    Na, Nt = cor.shape[:2]
+    f32 = lambda v: np.asarray(v, dtype=np.float64).astype(np.float32).astype(np.float64)
+    xf, yf = f32(g[..., 0] + veh.f2x * np.cos(g[..., 2])), f32(g[..., 1] + veh.f2x * np.sin(g[..., 2]))
+    xr, yr = f32(g[..., 0] + veh.r2x * np.cos(g[..., 2])), f32(g[..., 1] + veh.r2x * np.sin(g[..., 2]))
+    out = []
+    for a in range(Na):
+        out.append("agent%d:" % a)
+        for t in range(Nt):
+            c = cor[a, t]
+            out.append("  - [" + ", ".join(_g(v) for v in (xf[a, t], yf[a, t], c[0], c[1], c[2], c[3])) + "]")
+            out.append("  - [" + ", ".join(_g(v) for v in (xr[a, t], yr[a, t], c[4], c[5], c[6], c[7])) + "]")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+def read_corridors(path):
+    """Inverse of write_corridors: (centres [Na][Nt][4] = xf, yf, xr, yr, corridors [Na][Nt][8])."""
+    agents, cur = [], None
+    with open(path) as f:
+        for line in f:
+            body = line.strip()
+            if not body:
+                continue
+            if body.startswith("agent") and body.endswith(":"):
+                cur = []
+                agents.append(cur)
+            else:
+                cur.append([float(v) for v in body[body.index("[") + 1:body.rindex("]")].split(",")])
+    arr = np.array(agents, dtype=np.float64)                      # [Na][2 Nt][6]
+    front, rear = arr[:, 0::2], arr[:, 1::2]
+    centres = np.concatenate([front[..., :2], rear[..., :2]], -1)
+    return centres, np.concatenate([front[..., 2:], rear[..., 2:]], -1)
 
 
 def read_solutions(path):
@@ -140,9 +206,35 @@ def circle_rect_distance(p, obs, veh, margin=0.0):
     return np.hypot(np.maximum(lx, 0), np.maximum(ly, 0)) + np.minimum(np.maximum(lx, ly), 0) - ob[..., 2]
 
 
-def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0) -> ValidationReport:
-    """solutions [Na][Nt][>=3]; obstacles [n][3] = x, y, r.  `margin` inflates every vehicle rectangle on all sides."""
+def interpolate_states(solutions, frames_per_move):
+    """The poses the authors' animation checks, frame by frame (getState, scripts/visualize.py:256-281): frame f looks at
+    time f / frames_per_move; between two states x, y and yaw are interpolated linearly - `(next - last) * tau + last`, also
+    at whole times, where tau = 1 - after the earlier yaw has been moved by 2 pi towards the later one when they are more
+    than pi apart.  Returns [Na][(Nt - 1) * frames_per_move + 1][3]."""
+    sol = np.asarray(solutions, dtype=np.float64)[..., :3]
+    S = int(frames_per_move)
+    if S < 1:
+        raise ValueError("frames_per_move must be >= 1")
+    Na, Nt = sol.shape[:2]
+    f = np.arange((Nt - 1) * S + 1)
+    t = f / float(S)
+    idx = np.ceil(t).astype(np.int64)                               # first state whose time is >= t
+    last, nxt = sol[:, np.maximum(idx - 1, 0)].copy(), sol[:, idx]
+    dyaw = last[..., 2] - nxt[..., 2]
+    last[..., 2] = np.where(dyaw > np.pi, last[..., 2] - 2 * np.pi, np.where(-dyaw > np.pi, last[..., 2] + 2 * np.pi, last[..., 2]))
+    tau = (t - (idx - 1)) / 1
+    out = (nxt - last) * tau[None, :, None] + last
+    out[:, idx == 0] = sol[:, :1]
+    return out
+
+
+def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0, frames_per_move=None) -> ValidationReport:
+    """solutions [Na][Nt][>=3]; obstacles [n][3] = x, y, r.  `margin` inflates every vehicle rectangle on all sides.
+    frames_per_move = None: the Nt states as they are.  An integer S >= 1: the frames of the authors' animation
+    (interpolate_states: S frames per move, scripts/visualize.py:219-247); every index in the report is then a frame."""
     sol = np.asarray(solutions, dtype=np.float64)
+    if frames_per_move is not None:
+        sol = interpolate_states(sol, frames_per_move)
     Na, Nt = sol.shape[:2]
     c, u, hl, hw = _rect_frames(sol, veh)
     hl, hw = hl + margin, hw + margin

@@ -111,17 +111,23 @@ class DsqpHandle:
         lib().csdo_bridge_free(C.byref(bo))
         return out
 
-    def validate(self, solutions, veh, obstacles=None, dimx=0.0, dimy=0.0, margin=0.0):
-        """Trajectory validator on this GPU (csdo_validate); returns a results.ValidationReport."""
+    def validate(self, solutions, veh, obstacles=None, dimx=0.0, dimy=0.0, margin=0.0, frames_per_move=None):
+        """Trajectory validator on this GPU (csdo_validate; with frames_per_move = S >= 1 csdo_validate_frames: the frames
+        of the authors' animation, indices in the report are frames); returns a results.ValidationReport."""
         from .results import ValidationReport
         sol = np.ascontiguousarray(np.asarray(solutions, dtype=np.float64)[..., :6])
         if sol.shape[-1] < 6:
             sol = np.ascontiguousarray(np.concatenate([sol, np.zeros(sol.shape[:-1] + (6 - sol.shape[-1],))], -1))
         obs = np.zeros((0, 3)) if obstacles is None else np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 3)
         v = abi.Validation()
-        check(lib().csdo_validate(self._h, abi.as_double_p(sol), sol.shape[0], sol.shape[1], abi.as_double_p(obs),
-                                  obs.shape[0], float(dimx or 0.0), float(dimy or 0.0), C.byref(veh), float(margin),
-                                  C.byref(v)), "csdo_validate")
+        if frames_per_move is None:
+            check(lib().csdo_validate(self._h, abi.as_double_p(sol), sol.shape[0], sol.shape[1], abi.as_double_p(obs),
+                                      obs.shape[0], float(dimx or 0.0), float(dimy or 0.0), C.byref(veh), float(margin),
+                                      C.byref(v)), "csdo_validate")
+        else:
+            check(lib().csdo_validate_frames(self._h, abi.as_double_p(sol), sol.shape[0], sol.shape[1], int(frames_per_move),
+                                             abi.as_double_p(obs), obs.shape[0], float(dimx or 0.0), float(dimy or 0.0),
+                                             C.byref(veh), float(margin), C.byref(v)), "csdo_validate_frames")
         fv = tuple(v.first_vehicle) if v.vehicle_collisions else None
         fo = tuple(v.first_obstacle) if v.obstacle_collisions else None
         return ValidationReport(int(v.vehicle_collisions), int(v.obstacle_collisions), int(v.out_of_map), fv, fo,

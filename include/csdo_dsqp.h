@@ -17,6 +17,8 @@
  *                               call site csdo.cc:93-110.  Host code: the search is pointer-chasing, branchy and serial
  *   csdo_validate          <->  collision_rect_and_rect / collision_circle_and_rect over a result
  *                               scripts/collision_detection.py:20-96 (the authors' post-hoc check, scripts/visualize.py:219-247)
+ *   csdo_validate_frames   <->  the same per animation frame: Animation.getState + the prints of animate_func
+ *                               scripts/visualize.py:181-249,256-281
  *   csdo_generate_boxes    <->  generateBox                            sqp/corridor.h:84-88, .cc:124-159
  *   csdo_vehicle_default / csdo_qp_parm_default
  *                          <->  readAgentConfig / readQpSolverConfig   common/motion_planning.cc:54-93,
@@ -229,6 +231,13 @@ typedef struct csdo_validation {
 int csdo_validate(csdo_handle h, const double* solutions /* [Na][Nt][6] */, int32_t Na, int32_t Nt,
                   const double* obstacles /* [n_obs][3] */, int32_t n_obs, double dimx, double dimy,
                   const csdo_vehicle* veh, double margin, csdo_validation* out);
+/* The same check between the states: the authors' animation prints its collisions per FRAME, frames_per_move >= 1 frames per
+ * move (framesPerMove, scripts/visualize.py:27,186), looking at poses interpolated linearly in x, y and yaw between two states
+ * (getState, scripts/visualize.py:256-281, with its 2 pi yaw unwrapping; whole times go through the same formula).  The
+ * trajectory becomes (Nt - 1) * frames_per_move + 1 frames; every index in `out` is a frame index. */
+int csdo_validate_frames(csdo_handle h, const double* solutions /* [Na][Nt][6] */, int32_t Na, int32_t Nt,
+                         int32_t frames_per_move, const double* obstacles /* [n_obs][3] */, int32_t n_obs, double dimx,
+                         double dimy, const csdo_vehicle* veh, double margin, csdo_validation* out);
 
 /* Safe boxes for arbitrary points on the device (one lane per point). boxes: [n][4] x_min,y_min,x_max,y_max;
  * status: [n] bit0 = success, bits 1-2 = initial status (0 legal, 1 out of map, 2 collision). */

@@ -5,6 +5,10 @@ own Python tools (build container only: /root/reference does not exist on the GP
                                          Rectangle(pos='rear_axle_center') exactly as scripts/visualize.py:40-52 builds it)
   scripts/analysis_result.py:53-101      read_solution_status, the positional parser of the result YAML's header
 
+  scripts/visualize.py:256-281           Animation.getState (the interpolation between states the per-frame collision prints
+                                         of :219-247 look at) with check_collision / check_obs_collision of :40-52
+  scripts/visualize_corridor.py:92-103   translate2np, the parser of the corridor dump (sqp/utils.cc:62-89)
+
 The fixtures hold INPUTS (random poses / obstacle discs; a result file written by csdotrajectoryplanning_amd.results) and
 the reference's OUTPUTS (collision verdicts; parsed header values).  tests/test_results.py checks results.validate and
 results.write_solutions against them.   python tests/golden/make_ref_fixtures.py
@@ -88,5 +92,76 @@ def main():
     print("header cases:", [c["parsed"] for c in cases])
 
 
+def substep_and_corridor_fixtures():
+    """ref_substep_frames.npz: random trajectories (inputs) and, for 1, 3 and 10 frames per move, the reference's interpolated
+    poses and per-frame collision verdicts (outputs).  ref_corridor_parse.json: a corridor dump written by results.write_corridors
+    (text) and what the reference's parser makes of it."""
+    import yaml
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None          # the script asks for Qt5Agg at import; nothing is drawn here
+    import visualize as ref_vis                     # noqa: E402  (the reference's module)
+    import visualize_corridor as ref_vc             # noqa: E402
+    from csdotrajectoryplanning_amd import config, results
+    ref_vis.LF, ref_vis.LB, ref_vis.carWidth = LF, LB, W
+    rng = np.random.default_rng(20260303)
+    Na, Nt = 6, 9
+    # vehicles that pass close to each other and to two discs, with yaw crossing +-pi so that getState's unwrapping runs
+    sol = np.zeros((Na, Nt, 3))
+    for a in range(Na):
+        p = np.array([rng.uniform(18, 32), rng.uniform(18, 32)])
+        yaw = rng.uniform(-np.pi, np.pi)
+        for t in range(Nt):
+            sol[a, t] = [p[0], p[1], ((yaw + np.pi) % (2 * np.pi)) - np.pi]
+            yaw += rng.uniform(-0.5, 0.5)
+            p = p + rng.uniform(0.0, 2.2) * np.array([np.cos(yaw), np.sin(yaw)])
+    sol[0, :, 2] = np.linspace(2.6, 3.9, Nt)
+    sol[0, :, 2] = ((sol[0, :, 2] + np.pi) % (2 * np.pi)) - np.pi        # jumps from +pi to -pi between two states
+    obstacles = np.array([[25.0, 25.0, 0.8], [21.5, 28.0, 1.2], [29.0, 22.0, 0.8]])
+    sched = [[{"t": t, "x": float(sol[a, t, 0]), "y": float(sol[a, t, 1]), "yaw": float(sol[a, t, 2])} for t in range(Nt)]
+             for a in range(Na)]
+    out = dict(solutions=sol, obstacles=obstacles, LF=LF, LB=LB, W=W)
+    for S in (1, 3, 10):
+        nf = (Nt - 1) * S + 1
+        frames = np.zeros((Na, nf, 3))
+        veh_hits, obs_hits = [], []
+        for f in range(nf):
+            pos = [ref_vis.Animation.getState(None, f / S, sched[a]) for a in range(Na)]
+            for a in range(Na):
+                frames[a, f] = pos[a]
+            for i in range(Na):
+                for j in range(i + 1, Na):
+                    if ref_vis.check_collision(pos[i], pos[j]):
+                        veh_hits.append((f, i, j))
+            for a in range(Na):
+                for k, o in enumerate(obstacles):
+                    if ref_vis.check_obs_collision(pos[a], list(o)):
+                        obs_hits.append((f, a, k))
+        out["frames_%d" % S] = frames
+        out["vehicle_hits_%d" % S] = np.array(veh_hits, np.int64).reshape(-1, 3)
+        out["obstacle_hits_%d" % S] = np.array(obs_hits, np.int64).reshape(-1, 3)
+        print("frames per move %d: %d frames, %d vehicle and %d obstacle collision triples" % (S, nf, len(veh_hits), len(obs_hits)))
+    np.savez_compressed(os.path.join(HERE, "ref_substep_frames.npz"), **out)
+
+    veh = config.vehicle_from_config()
+    x0 = np.zeros((2, 3, 6))
+    x0[..., 0] = [[10.0, 11.5, 13.0], [40.25, 40.25, 41.0]]
+    x0[..., 1] = [[7.0, 7.125, 7.5], [33.0, 34.0, 35.5]]
+    x0[..., 2] = [[0.0, 0.3, 0.6], [-1.57, -1.2, 3.1]]
+    cor = rng.uniform(0.0, 50.0, (2, 3, 8))
+    cor[0, 0] = [1.25, 20.1000000001, 1.25, 9.99999999, 1.25, 123456.789, 0.0625, 48.75]   # (PyYAML reads 1e-05 as a string)
+    path = os.path.join(HERE, "_tmp_corridors.yaml")
+    results.write_corridors(path, cor, x0, veh)
+    with open(path) as f:
+        text = f.read()
+    with open(path) as f:
+        parsed = ref_vc.translate2np(yaml.load(f, Loader=yaml.FullLoader))
+    os.remove(path)
+    with open(os.path.join(HERE, "ref_corridor_parse.json"), "w") as f:
+        json.dump(dict(generator="tests/golden/make_ref_fixtures.py", parser="scripts/visualize_corridor.py:92-103",
+                       x0_bar=x0.tolist(), corridors=cor.tolist(), yaml_text=text, parsed=parsed.tolist()), f, indent=1)
+    print("corridor dump parsed by the reference:", parsed.shape)
+
+
 if __name__ == "__main__":
     main()
+    substep_and_corridor_fixtures()

@@ -98,3 +98,37 @@ def test_device_validator_equals_numpy_validator_on_results(gpu_handle, which, k
         assert got.first_vehicle_collision == ref.first_vehicle_collision
         assert got.first_obstacle_collision == ref.first_obstacle_collision
         assert abs(got.min_obstacle_clearance - ref.min_obstacle_clearance) < 1e-9
+
+
+def test_device_validator_between_states_equals_the_references_frames(gpu_handle, veh_parm):
+    """csdo_validate_frames against the per-frame verdicts of scripts/visualize.py:219-247 with getState's interpolation
+    (fixture generated by importing the reference's script: tests/golden/make_ref_fixtures.py)."""
+    from csdotrajectoryplanning_amd import results
+    veh, _ = veh_parm
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_substep_frames.npz"))
+    for S in (1, 3, 10):
+        vh, oh = z["vehicle_hits_%d" % S], z["obstacle_hits_%d" % S]
+        got = gpu_handle.validate(z["solutions"], veh, z["obstacles"], frames_per_move=S)
+        assert (got.vehicle_collisions, got.obstacle_collisions) == (len(vh), len(oh))
+        assert got.first_vehicle_collision == tuple(int(v) for v in min(map(tuple, vh)))
+        assert got.first_obstacle_collision == tuple(int(v) for v in min(map(tuple, oh)))
+        ref = results.validate(z["solutions"], veh, z["obstacles"], frames_per_move=S)
+        assert abs(got.min_obstacle_clearance - ref.min_obstacle_clearance) < 1e-9
+
+
+@pytest.mark.parametrize("which,k", [("map50", 3), ("map100", 1)])
+def test_device_validator_between_states_on_results(gpu_handle, which, k):
+    """A DO-phase result checked at 5 frames per move: device == numpy, and no more collisions appear between the states
+    than the timestep check plus what a neighbouring state already shows (the trajectories are 0.7 m per step)."""
+    from csdotrajectoryplanning_amd import results
+    w, _ = _paths(k, which)
+    sol = gpu_handle.solve(w).solutions
+    ref = results.validate(sol, w.veh, w.obstacles, w.dimx, w.dimy, frames_per_move=5)
+    got = gpu_handle.validate(sol, w.veh, w.obstacles, w.dimx, w.dimy, frames_per_move=5)
+    assert (got.vehicle_collisions, got.obstacle_collisions, got.out_of_map) == \
+           (ref.vehicle_collisions, ref.obstacle_collisions, ref.out_of_map)
+    assert got.first_vehicle_collision == ref.first_vehicle_collision
+    assert got.first_obstacle_collision == ref.first_obstacle_collision
+    assert abs(got.min_obstacle_clearance - ref.min_obstacle_clearance) < 1e-9
+    coarse = gpu_handle.validate(sol, w.veh, w.obstacles, w.dimx, w.dimy)
+    assert got.min_obstacle_clearance <= coarse.min_obstacle_clearance + 1e-9

@@ -15,14 +15,22 @@ its block overlaps, solves its block, and the step ends with the path's only col
 trajectories on the device pointer.
 --scaling weak        (default) the job is N copies of the workload (the stand-in worlds of copy c seeded with 60 c): the
                       per-GPU work is fixed as N grows
---scaling strong      the job is ONE copy of the workload whatever N: bounded by its longest agent (45 ms against 83 ms / N)
+--scaling strong      the job is ONE copy of the workload whatever N - BASELINE configs[3] / [4] read literally: one workload
+                      at 1 / 2 / 4 / 8 GPUs.  Its floor is the workload's longest agent (map100: ~40 ms of a ~80 ms step), so
+                      the expected curve is 80 -> ~47 -> ~42 -> ~40 ms, not 1/N
+Blocks are balanced by the launcher's own per-agent work estimate (csdo_dsqp_estimate_work), not by agent count.
+--force-dist          N = 1 with a one-rank "nccl" group: RCCL initialisation, the all-gather on the solver's device buffer
+                      and the stream ordering run on the one GPU there is
 Rank 0 prints ONE JSON line.
 
 metric  = agent-QP-iterations/sec: ADMM iterations executed by all agents of all ranks / wall time of the K steps (max
-          over ranks).  `single_instance` (ex0 alone) is the metric's "DO-phase ms, 50-agent instance";
-          `do_phase_e2e` is the batch's PCIe-inclusive DO phase (bridge on all host cores + H2D + kernels + D2H), never
-          `value`.
-roofline: nominal HBM roofline of SURVEY 8(d): algorithmic bytes W_iter = 2280*Nt + 416*K_a per agent-iteration summed
+          over ranks): kernels only, inputs resident in HBM.  `value_e2e` is the same count over the PCIe-inclusive DO phase
+          of csdo.cc:111-148 (`do_phase_e2e`: bridge with its pair search on the device + pack + H2D + kernels + D2H +
+          scatter, host wall clock, nothing resident); `single_instance` (ex0 alone) is the metric's "DO-phase ms, 50-agent
+          instance".
+roofline: `fp64` and `lds` price the ADMM iterations against the two resources the kernel actually uses (DESIGN section 5 writes
+          the counts out: F_iter = 718 Nt + 88 K + 2592 flop and L_iter = 8 (139 Nt + 42 K + 1440) LDS bytes per agent-iteration,
+          against 78.6 TFLOP/s fp64 vector and 157 TB/s LDS); the contract's figure is the nominal HBM roofline of SURVEY 8(d): algorithmic bytes W_iter = 2280*Nt + 416*K_a per agent-iteration summed
           over the iterations the dominant kernel's launch executes / that kernel's average duration (HIP events on the
           launch stream inside csdo_dsqp_run) against 8 TB/s.  The working set is on-chip, so the kernel is latency
           bound, not HBM bound: `traffic` (HBM bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes),
@@ -125,6 +133,8 @@ def main():
                          "batch launches free of the small launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive DO-phase measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: run the sharded path with a one-rank nccl group (RCCL init, all-gather on the device buffer)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +142,7 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     strong = world_size > 1 and args.scaling == "strong"
     copies = 1 if (strong or world_size == 1) else world_size
+    sharded = world_size > 1 or args.force_dist
 
     # torch first: it brings its own HIP runtime, which must be the one libcsdo_hip.so binds to (loading the library
     # before torch puts two runtimes into the process and aborts under rocprofv3); importing does not touch the GPU
@@ -145,17 +156,44 @@ def main():
     for c in range(copies):
         jobs += workloads.workload_jobs(args.workload, args.instances, seed_offset=60 * c, front=args.front)
     sizes = [workloads.job_agents(j) for j in jobs]
-    if world_size > 1:   # this rank only builds the worlds its block of agents overlaps
-        plan = sharding.shard_batch_plan(sizes, rank, world_size)
+
+    def _build_all(js):
+        procs = min(len(js), os.cpu_count() or 1, max(args.setup_procs, 1))
+        if procs > 1:
+            with get_context("fork").Pool(procs) as pool:
+                return pool.map(_build, js)
+        return [_build(j) for j in js]
+
+    shard_balance = None
+    if sharded:
+        # blocks of equal estimated WORK (the launcher's own estimate), not of equal agent count: every rank builds copy 0 of the
+        # workload for the estimates (the copies of a weak-scaling job differ only in the seeds of the few stand-in worlds)
+        import numpy as _np
+        from csdotrajectoryplanning_amd.solver import estimate_work
+        base = jobs[:len(jobs) // copies]
+        built0 = _build_all(base)
+        est = _np.tile(estimate_work([w for w, _ in built0]), copies)
+        plan = sharding.shard_batch_plan(sizes, rank, world_size, weights=est)
+        loads = [float(est[lo:hi].sum()) for lo, hi in sharding.shard_bounds_weighted(est, world_size)]
+        by_count = [float(est[lo:hi].sum()) for lo, hi in sharding.shard_bounds(len(est), world_size)]
+        shard_balance = {"estimated_work_max_over_mean": max(loads) / (sum(loads) / len(loads)),
+                         "if_balanced_by_agent_count": max(by_count) / (sum(by_count) / len(by_count))}
+        my_jobs = [jobs[w] for w, _, _ in plan]
+        built = []
+        todo = []
+        for w, _, _ in plan:
+            c, k = divmod(w, len(base))
+            if c == 0 or str(built0[k][1]["generator"]).startswith("front_end"):
+                built.append(built0[k])
+            else:
+                built.append(None)
+                todo.append((len(built) - 1, jobs[w]))
+        for (slot, _), b in zip(todo, _build_all([j for _, j in todo]) if todo else []):
+            built[slot] = b
     else:
         plan = [(w, 0, n) for w, n in enumerate(sizes)]
-    my_jobs = [jobs[w] for w, _, _ in plan]
-    procs = min(len(my_jobs), os.cpu_count() or 1, max(args.setup_procs, 1))
-    if procs > 1:
-        with get_context("fork").Pool(procs) as pool:
-            built = pool.map(_build, my_jobs)
-    else:
-        built = [_build(j) for j in my_jobs]
+        my_jobs = [jobs[w] for w, _, _ in plan]
+        built = _build_all(my_jobs)
     worlds, infos = [], []
     for (w, lo, hi), (world, info) in zip(plan, built):
         worlds.append(world if (lo == 0 and hi == world.Na) else world.subset(lo, hi))
@@ -172,9 +210,10 @@ def main():
 
     dist = None
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
         dist.init_process_group(backend="nccl", rank=rank, world_size=world_size)
     dev = torch.device("cuda", local_rank)
     # an explicit (non-null) stream: the solver's kernels, the copy into the send buffer and the collective are all
@@ -251,7 +290,7 @@ def main():
     ptr, n_dbl = h.device_solutions()
     sol_dev = torch.as_tensor(_DevArray(ptr, n_dbl), device=dev)
     fg = None
-    if world_size > 1:
+    if sharded:
         with torch.cuda.stream(tstream):
             fg = sharding.FlatGather(n_dbl, dist, dev)     # ranks differ in sum(Nt): padded to the largest
         tstream.synchronize()
@@ -291,43 +330,56 @@ def main():
     bytes_agent = np.concatenate([algorithmic_bytes(w, s.admm_iters) for w, s in zip(worlds, sols)])
     iters_agent = np.concatenate([s.admm_iters for s in sols])
 
-    # ---- the PCIe-inclusive DO phase of the batch (csdo.cc:111-148: preprocess + SolverDSQP), outside the timed region:
-    # bridge of every world on the host cores, steady-state upload, one solve, download
+    # ---- the PCIe-inclusive DO phase of the batch (csdo.cc:111-148: preprocess + SolverDSQP), outside the timed region, host
+    # wall clock around everything, nothing resident: bridge of every world (ONE csdo_preprocess_device_batch call: host
+    # interpolation on a thread pool, pair search + planes on the device), then csdo_dsqp_solve_batch's three stages
     e2e = None
     if not args.no_e2e and rank == 0:
         from concurrent.futures import ThreadPoolExecutor
+        items = [(*infos[i]["paths"], worlds[i].dimx, worlds[i].dimy, worlds[i].obstacles) for i in range(len(worlds))
+                 if worlds[i].Na == len(infos[i]["paths"][2]) - 1]
+        whole = [i for i in range(len(worlds)) if worlds[i].Na == len(infos[i]["paths"][2]) - 1]
+        h.interpolate_and_planes_batch(items[:2], w0.veh, w0.parm)      # (first call: device buffers, page-locked staging)
+        best = None
+        for _ in range(3):
+            t_b0 = time.perf_counter()
+            bridged = h.interpolate_and_planes_batch(items, w0.veh, w0.parm)
+            t_bridge_dev = time.perf_counter() - t_b0
+            bw = [worlds[i] for i in range(len(worlds))]
+            for i, (bworld, _, _) in zip(whole, bridged):
+                bw[i] = bworld
+            t_u0 = time.perf_counter()
+            h.upload(bw)
+            t_upload = time.perf_counter() - t_u0
+            t_k0 = time.perf_counter()
+            t_k = h.run(stream)
+            t_kw = time.perf_counter() - t_k0
+            t_d0 = time.perf_counter()
+            h.download()
+            t_dl = time.perf_counter() - t_d0
+            tot = time.perf_counter() - t_b0
+            if best is None or tot < best[0]:
+                best = (tot, t_bridge_dev, t_upload, t_k, t_kw, t_dl, h.transfer_seconds())
+        tot, t_bridge_dev, t_upload, t_k, t_kw, t_dl, xfer = best
 
         def _bridge(i):
             st, ac, po, G = infos[i]["paths"]
             w = worlds[i]
             return interpolate_and_planes(st, ac, po, G, w.veh, w.parm, w.dimx, w.dimy, w.obstacles)[0]
-        nthr = min(len(worlds), os.cpu_count() or 1)
-        with ThreadPoolExecutor(nthr) as ex:      # ctypes releases the GIL inside csdo_preprocess
-            list(ex.map(_bridge, range(min(2, len(worlds)))))
+        nthr = min(len(whole), os.cpu_count() or 1)
+        with ThreadPoolExecutor(nthr) as ex:      # the host bridge beside it (ctypes releases the GIL inside csdo_preprocess)
+            list(ex.map(_bridge, whole[:2]))
             t_b0 = time.perf_counter()
-            list(ex.map(_bridge, range(len(worlds))))
+            list(ex.map(_bridge, whole))
             t_bridge = time.perf_counter() - t_b0
-        t_k0 = time.perf_counter()
-        for i in range(len(worlds)):       # the same bridge with the O(Nt Na^2) stages on the device (csdo_preprocess_device)
-            st_, ac_, po_, G_ = infos[i]["paths"]
-            w_ = worlds[i]
-            h.interpolate_and_planes(st_, ac_, po_, G_, w_.veh, w_.parm, w_.dimx, w_.dimy, w_.obstacles)
-        t_bridge_dev = time.perf_counter() - t_k0
-        t_u0 = time.perf_counter()
-        h.upload(worlds)
-        t_upload = time.perf_counter() - t_u0
-        t_k = h.run(stream)
-        t_d0 = time.perf_counter()
-        h.download()
-        t_dl = time.perf_counter() - t_d0
-        xfer = h.transfer_seconds()
-        tot = t_bridge + t_upload + t_k + t_dl
-        e2e = {"bridge_host_ms": t_bridge * 1e3, "bridge_threads": nthr, "bridge_device_k0_serial_ms": t_bridge_dev * 1e3, "upload_h2d_ms": t_upload * 1e3,
-               "upload_h2d_first_call_ms": t_upload_first * 1e3, "solve_kernels_ms": t_k * 1e3,
-               "download_d2h_ms": t_dl * 1e3, "total_ms": tot * 1e3,
+        e2e = {"total_ms": tot * 1e3, "bridge_device_batch_ms": t_bridge_dev * 1e3, "upload_pack_h2d_ms": t_upload * 1e3,
+               "solve_kernels_ms": t_k * 1e3, "solve_host_wall_ms": t_kw * 1e3, "download_d2h_scatter_ms": t_dl * 1e3,
+               "upload_first_call_ms": t_upload_first * 1e3,
                "library_breakdown_ms": {k: v * 1e3 for k, v in xfer.items()},
+               "bridge_host_threads_ms": t_bridge * 1e3, "bridge_host_threads": nthr,
                "agent_qp_iterations_per_sec": iters_step / tot,
-               "note": "PCIe-inclusive DO phase of rank 0's batch; never `value`"}
+               "note": "PCIe-inclusive DO phase of rank 0's batch, best of 3, host wall clock from the coarse paths to the "
+                       "results in the caller's arrays; never `value`"}
 
     # ---- the authors' own acceptance of a result: the trajectory validator (device kernel), per world
     validation = None
@@ -380,6 +432,13 @@ def main():
         traffic, hbm_frac, valu_frac, pmc_src = (None, None, None, None)
         if world_size == 1:
             traffic, hbm_frac, valu_frac, pmc_src = _newest_pmc(args.workload, elapsed_max / steps * 1e3)
+        # what the ADMM iterations cost in the two resources the kernel does use (counts per agent-iteration)
+        K_agent = np.concatenate([(w.plane_off[1:] - w.plane_off[:-1]).astype("float64") for w in worlds])
+        Nt_agent = np.concatenate([np.full(w.Na, float(w.Nt)) for w in worlds])
+        it_f = iters_agent.astype("float64")
+        flops_step = float((it_f * (718.0 * Nt_agent + 88.0 * K_agent + 2592.0)).sum())
+        lds_bytes_step = float((it_f * 8.0 * (139.0 * Nt_agent + 42.0 * K_agent + 1440.0)).sum())
+        FP64_PEAK_TF, LDS_PEAK_TBS = 78.6, 157.0
         Nts = sorted(w.Nt for w in worlds)
         n_agents = int(sum(w.Na for w in worlds))
         wl_names = {"map100": "map100by100/agents50/obstacle set", "map50": "map50by50/agents25/obstacle set",
@@ -397,7 +456,11 @@ def main():
             "scaling": "weak" if (world_size == 1 or not strong) else "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "the reference's benchmark instance files (tests/golden/instances = benchmark/map100by100, map50by50, room of "
+                    "the reference); coarse paths from this repository's own front end, stored; no synthetic maps",
+            "value_e2e": (e2e["agent_qp_iterations_per_sec"] if e2e else None),
+            "value_is": "kernels only, inputs resident in HBM (the contract's `value`); value_e2e = the same iterations over the "
+                        "PCIe-inclusive DO phase (do_phase_e2e.total_ms)",
             "config": {
                 "workload": "%s: %d worlds, %d agents on rank 0 in one batch, Nt %d..%d, %d inter-vehicle planes; "
                             "benchmark instance files; %s"
@@ -418,7 +481,9 @@ def main():
                                  if strong else
                                  "%d copies of the workload, agents sharded in contiguous blocks over %d ranks"
                                  % (copies, world_size))),
-                "collective": "all_gather(final trajectories, device pointers) per step" if world_size > 1 else "none",
+                "collective": ("all_gather(final trajectories, device pointers) per step" +
+                               (" on a ONE-rank nccl group (--force-dist)" if world_size == 1 else "")) if sharded else "none",
+                "shard_balance": shard_balance,
                 "per_rank": per_rank,
             },
             "single_instance": single,
@@ -430,7 +495,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "binding": "dependency latency (LDS exchange + barriers + fp64 issue) of one workgroup per agent; "
-                                    "the working set is on-chip, `frac` is the nominal SURVEY 8(d) figure",
+                                    "the working set is on-chip: `frac` is the NOMINAL SURVEY 8(d) figure (it prices every "
+                                    "iteration as if factor, rows and iterate streamed from HBM, and passes 1.0 as the kernel "
+                                    "gets faster); of the real resources HBM is the closest to its peak (hbm_counter_frac), "
+                                    "then fp64 issue and LDS (fp64.frac, lds.frac)",
+                         "fp64": {"achieved": flops_step / kernel_avg / 1e12, "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": flops_step / kernel_avg / 1e12 / FP64_PEAK_TF,
+                                  "flop_per_agent_iteration": "718 Nt + 88 K + 2592 (ADMM iterations only)"},
+                         "lds": {"achieved": lds_bytes_step / kernel_avg / 1e12, "peak": LDS_PEAK_TBS, "unit": "TB/s",
+                                 "frac": lds_bytes_step / kernel_avg / 1e12 / LDS_PEAK_TBS,
+                                 "bytes_per_agent_iteration": "8 (139 Nt + 42 K + 1440) (ADMM iterations only)"},
                          "hbm_counter_frac": hbm_frac, "valu_fp64_issue_frac": valu_frac, "pmc_source": pmc_src,
                          "kernel": "dsqp_agent_kernel<%d, %d, true>" % (dom["threads"], dom["residency_mode"]),
                          "kernel_avg_ms": dom_avg * 1e3, "algorithmic_bytes_per_launch": gbytes[gd],

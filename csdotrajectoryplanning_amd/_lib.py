@@ -6,7 +6,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsdo_hip.so")
+# (CSDO_DIAG_LIB: diagnostic builds of the same library - phase timers, A/B kernel experiments - for scripts/; never set in tests)
+LIB_PATH = os.environ.get("CSDO_DIAG_LIB") or os.path.join(_HERE, "libcsdo_hip.so")
 _LIB = None
 
 
@@ -53,6 +54,11 @@ def lib():
         L.csdo_preprocess.argtypes = [abi.c_double_p, abi.c_int32_p, abi.c_int32_p, C.c_int32, abi.c_double_p,
                                       C.POINTER(abi.Vehicle), C.POINTER(abi.QpParm), C.POINTER(abi.BridgeOut)]
         L.csdo_preprocess_device.argtypes = [H] + L.csdo_preprocess.argtypes
+        PP = C.POINTER
+        L.csdo_preprocess_device_batch.argtypes = [H, C.c_int32, PP(abi.c_double_p), PP(abi.c_int32_p), PP(abi.c_int32_p),
+                                                   abi.c_int32_p, PP(abi.c_double_p), PP(abi.Vehicle), PP(abi.QpParm),
+                                                   PP(abi.BridgeOut)]
+        L.csdo_dsqp_estimate_work.argtypes = [PP(abi.Problem), C.c_int32, abi.c_double_p]
         L.csdo_validate.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                     C.c_double, C.POINTER(abi.Vehicle), C.c_double, C.POINTER(abi.Validation)]
         L.csdo_validate_frames.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32,

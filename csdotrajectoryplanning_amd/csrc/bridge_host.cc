@@ -234,12 +234,17 @@ bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* ve
 // [n_pairs][24] (agent i's 12 then agent j's 12, e.g. from the device kernel) or null to compute them here.
 int bridge_planes(const BridgeCentres& C, const std::vector<int32_t>& pairs, const csdo_vehicle* vehp, const double* coef,
                   csdo_bridge_out* out) {
+  return bridge_planes(C, pairs.data(), pairs.size() / 3, vehp, coef, out);
+}
+
+int bridge_planes(const BridgeCentres& C, const int32_t* pairs, size_t n_pairs_in, const csdo_vehicle* vehp, const double* coef,
+                  csdo_bridge_out* out) {
   const Veh v{(float)vehp->r, (float)vehp->LF, (float)vehp->LB, (float)vehp->car_width,
               (float)vehp->f2x, (float)vehp->r2x, (float)vehp->rv};
   const int Na = C.Na;
   const size_t Nt = (size_t)C.Nt;
   const std::vector<float>&xf = C.xf, &yf = C.yf, &xr = C.xr, &yr = C.yr;
-  const int n_pairs = (int)(pairs.size() / 3);
+  const int n_pairs = (int)n_pairs_in;
   // ---- separating planes (calcEqualInterPlanes :71-140, calcPerpendicular :54-69) ----
   std::vector<int32_t> cnt(Na + 1, 0);
   for (int p = 0; p < n_pairs; ++p) {
@@ -256,7 +261,7 @@ int bridge_planes(const BridgeCentres& C, const std::vector<int32_t>& pairs, con
     return CSDO_ENOMEM;
   }
   std::memcpy(out->plane_off, cnt.data(), sizeof(int32_t) * (Na + 1));
-  if (n_pairs) std::memcpy(out->pairs, pairs.data(), sizeof(int32_t) * 3 * (size_t)n_pairs);
+  if (n_pairs) std::memcpy(out->pairs, pairs, sizeof(int32_t) * 3 * (size_t)n_pairs);
   std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
   const double rv = v.rv;
   for (int p = 0; p < n_pairs; ++p) {

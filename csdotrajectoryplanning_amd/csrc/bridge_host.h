@@ -4,6 +4,7 @@
 // O(Na*Nt) interpolation and O(Nt*Na^2) pair search on precomputed float disc centres: host work by design
 // (SURVEY 8a rows a2-a4), it is ~1 ms at 50 agents.
 #pragma once
+#include <cstddef>
 #include <vector>
 
 #include "../../include/csdo_dsqp.h"
@@ -22,6 +23,8 @@ int bridge_interpolate(const double* states, const int32_t* actions, const int32
 bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* veh, std::vector<int32_t>& pairs);
 int bridge_planes(const BridgeCentres& C, const std::vector<int32_t>& pairs, const csdo_vehicle* veh, const double* coef,
                   csdo_bridge_out* out);
+int bridge_planes(const BridgeCentres& C, const int32_t* pairs, size_t n_pairs, const csdo_vehicle* veh, const double* coef,
+                  csdo_bridge_out* out);   // the same on a slice of a batch's pair list
 int bridge_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                       const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
 void bridge_free(csdo_bridge_out* out);

@@ -203,6 +203,13 @@ CSDO_FN double limit_scaling(double d) {
   d = d > MAX_SCALING ? MAX_SCALING : d;
   return d;
 }
+// maxima of absolute values (accumulator a >= 0, never NaN; a NaN in b is ignored like dmax does): one v_max_f64
+CSDO_FN double nmax(double a, double b) { return __builtin_fmax(a, b); }
+// limit_scaling of such a maximum (d >= 0, never NaN): the upper clamp as one v_min_f64
+CSDO_FN double limit_norm(double d) {
+  d = d < MIN_SCALING ? 1.0 : d;
+  return __builtin_fmin(d, MAX_SCALING);
+}
 CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -224,6 +231,7 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   double y[NROW], z[NROW];  // ADMM dual / slack (z doubles as Ruiz scratch before the warm start)
   double x[6];              // scaled primal iterate
   double b[6];              // Ruiz scratch / rhs temporary
+  double dsc[6];            // accumulated Ruiz column scaling D (set-up stage; kept in the workspace afterwards)
   double Pvv, Pww, Pvn;     // scaled objective (set-up stage; kept in the workspace afterwards)
   unsigned eqmask;          // rows in OSQP's "equality" class (rho * 1e3)
   unsigned loosemask;       // rows with both bounds infinite (rho = RHO_MIN)
@@ -376,6 +384,46 @@ CSDO_FN void red_fold(const Shm& sh, int Nt, double (&out)[K]) {
       for (int l = 0; l < off; ++l) lane[l] = IS_SUM ? (lane[l] + lane[l + off]) : dmax(lane[l], lane[l + off]);
     out[k] = lane[0];
   });
+#endif
+}
+
+// *addr = max(*addr, v) for non-negative finite doubles held in LDS, from any thread of the workgroup: the bit patterns of
+// non-negative doubles order like unsigned integers, so this is one ds_max_u64.  NaN and zero leave the maximum alone (dmax).
+CSDO_FN void lds_max_nonneg(double* addr, double v) {
+  if (v > 0.0) {
+#if defined(CSDO_LANE_MODE_DEVICE)
+    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+#else
+    if (v > *addr) *addr = v;
+#endif
+  }
+}
+
+// Sum over lanes 0..Nt-1 of the field-major array field[k * stride + t], in red_fold's order (stride-64 serial, then a
+// halving tree).  Collective; the caller has a barrier between the writes of the field and this call.
+CSDO_FN void field_sum(const Shm& sh, int Nt, int k, double (&out)[1]) {
+  const double* f = sh.vec + (size_t)k * (size_t)sh.stride;
+#if defined(CSDO_LANE_MODE_DEVICE)
+  const int tid = (int)threadIdx.x;
+  if (tid < 64) {
+    double acc = 0.0;
+    for (int j = tid; j < Nt; j += 64) acc = acc + f[j];
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + wave_shfl_down(acc, off);
+    if (tid == 0) sh.bcast[0] = acc;
+  }
+  __syncthreads();
+  out[0] = uniform_f64(sh.bcast[0]);
+  __syncthreads();
+#else
+  double lane[64];
+  for (int l = 0; l < 64; ++l) {
+    double acc = 0.0;
+    for (int j = l; j < Nt; j += 64) acc = acc + f[j];
+    lane[l] = acc;
+  }
+  for (int off = 32; off >= 1; off >>= 1)
+    for (int l = 0; l < off; ++l) lane[l] = lane[l] + lane[l + off];
+  out[0] = lane[0];
 #endif
 }
 

@@ -17,6 +17,8 @@ namespace csdo {
 // everything from the workspace for long horizons
 #define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t))))
 #define SINV(k, t) (MODE >= 1 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
+// set-up stage scratch, field-major over the ADMM block's exchange arrays (see "assemble the QP")
+#define SU(k, t) sh.vec[(size_t)(k) * (size_t)sh.stride + (unsigned)(t)]
 #define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 #define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
 // mode 0, between ADMM blocks: y (0..15), z (16..31), x (32..37) of the iterate a block has just finished, field-major in the
@@ -44,7 +46,6 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
     CSDO_FOR(s, 3, { S.c[i][s] = 0.0; });
     S.lo[i] = 0.0;
     S.hi[i] = 0.0;
-    CD(C_E + i, t) = 1.0;
   });
   CSDO_FOR(i, 4, { S.cn[i] = 0.0; });
   unsigned act = 0x0780u | 0x1800u | 0x8000u;  // corridor, trust, steer rows exist at every t
@@ -116,7 +117,6 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
   S.Pvv = (t < Nm) ? ((t == 0 || t == Nt - 2) ? 1.0 : 2.0) : 0.0;
   S.Pvn = (t <= Nt - 3) ? -1.0 : 0.0;
   S.Pww = (t < Nm) ? 1.0 : 0.0;
-  CSDO_FOR(j, 6, { CD(C_D + j, t) = 1.0; });
 }
 
 // =========================================================================================================
@@ -623,36 +623,43 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   CSDO_PHASE(2);
     // ============================================================== assemble the QP (unscaled)
     CSDO_MARK("assemble");
-    // The inter-vehicle rows' coefficients and scalings are read and rewritten row by row in each of the ten equilibration
-    // passes.  In the workspace every such access is a trip to HBM (the workspaces of the agents sharing an XCD do not fit
-    // its L2) and the rows of a timestep are a serial chain: 40 k cycles per pass.  During the set-up stages the ADMM
-    // block's LDS arrays are idle, so the four fields live in the `fx` part of them (fields x 4K rows) whenever they fit, and
-    // the warm-start stage publishes them to the workspace.
-    const bool rz_lds = (MODE == 0) && ((int64_t)16 * ad.n_planes <= (int64_t)LD_fx * sh.stride);
-    auto rz = [&](const int r, const int f_lds, const int f_ws) __attribute__((always_inline)) -> double& {
+    // Set-up stage storage.  SU(k, t): field-major scratch over the ADMM block's exchange arrays, which are idle here (every
+    // residency mode has >= 30 fields): 0..3 |cn| and 4 |Pvn| for t+1; 5..9 the column factors D_t[0..4] of the pass (for t-1
+    // and for the inter-vehicle rows), after the last pass the scaled x of the warm start; 10..12 column maxima of the
+    // timestep's inter-vehicle rows; 13 the cost-scaling partial; 14..29 the accumulated row scalings E (14..21 first carry the
+    // disc linearisation of the timestep to the threads that assemble the inter-vehicle rows).
+    // The inter-vehicle rows (a, b, c_yaw, E, u per row, the timestep per plane) live in the `fx` part of the block's arrays
+    // whenever they fit (fields x 4K rows), else in the workspace, and ALL work on them is done row by row by the solver
+    // threads, beside the row lanes: assembled and scaled by the rows of a timestep's lane they were a serial chain with a
+    // reciprocal square root per row and pass (and, in the workspace, a trip to HBM per access): 30 k cycles per pass.
+    // Column maxima reach the timestep's lane through an LDS maximum (order independent), its column factors come back
+    // through SU: same operations on the same operands as OSQP's scale_data, same results.
+    const bool rz_lds = (MODE == 0) && ((int64_t)21 * ad.n_planes <= (int64_t)LD_fx * sh.stride);
+    auto rz = [&](const int r, const int f_lds, const int f_ws) __attribute__((always_inline)) -> double& {   // f_lds: a, b, c_yaw, E, u
       return rz_lds ? sh.fx[(size_t)f_lds * (size_t)rcap + (unsigned)r] : ROW(r, f_ws);
+    };
+    auto rz_time = [&](const int pl_) __attribute__((always_inline)) -> int {
+      return rz_lds ? (int)sh.fx[(size_t)5 * (size_t)rcap + (unsigned)pl_] : (int)planes[pl_].t;
     };
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       double dfx, dfy, drx, dry, exf, eyf, exr, eyr;
       assemble_home_rows(S, sh, t, Nt, P, dfx, dfy, drx, dry, exf, eyf, exr, eyr);
-      // inter-vehicle rows at t (calcInterVehicleConstraint :1097-1129): row = [a, b, a*Dx + b*Dy] on (x,y,yaw)_t,
-      // upper bound -(c + (a*Ex + b*Ey)), lower bound -inf
-      for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
-        const PlaneDev& pl = planes[k];
-        CSDO_FOR(r, 4, {
-          const double a = pl.c[3 * r], bb = pl.c[3 * r + 1], cc = pl.c[3 * r + 2];
-          const double Dx = (r < 2) ? dfx : drx, Dy = (r < 2) ? dfy : dry;
-          const double Ex = (r < 2) ? exf : exr, Ey = (r < 2) ? eyf : eyr;
-          const int rr = 4 * k + r;
-          rz(rr, 0, R_CA) = a;
-          rz(rr, 1, R_CB) = bb;
-          rz(rr, 2, R_CY) = a * Dx + bb * Dy;
-          ROW(rr, R_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
-          rz(rr, 3, R_E) = 1.0;
-        });
+      SU(14, t) = dfx; SU(15, t) = dfy; SU(16, t) = drx; SU(17, t) = dry;
+      SU(18, t) = exf; SU(19, t) = eyf; SU(20, t) = exr; SU(21, t) = eyr;
+      SU(10, t) = 0.0; SU(11, t) = 0.0; SU(12, t) = 0.0;
+      CSDO_FOR(j, 6, { S.dsc[j] = 1.0; });
+      // the (unscaled) bounds wait in the workspace until the warm start: 32 doubles less in the equilibration's registers
+      CSDO_FOR(i, NROW, {
+        WS(W_LO + i, t) = S.lo[i];
+        WS(W_HI + i, t) = S.hi[i];
+      });
+      if (t == 0) {
+        sh.bcast[30] = 0.0;
+        sh.bcast[31] = 0.0;
       }
     }
+    CSDO_SYNC();
 
   CSDO_PHASE(3);
     // ============================================================== Ruiz equilibration (scaling.c scale_data)
@@ -661,8 +668,47 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     for (int pass = 0; pass < P.scaling_passes; ++pass) {
       CSDO_LANES(t) {  // hand |cn| and |Pvn| to t+1
         LaneState& S = CSDO_LS(t);
-        CSDO_FOR(k, 4, { SH(carry, k, t) = fabs(S.cn[k]); });
-        SH(carry, 4, t) = fabs(S.Pvn);
+        CSDO_FOR(k, 4, { SU(k, t) = fabs(S.cn[k]); });
+        SU(4, t) = fabs(S.Pvn);
+      }
+      CSDO_STHREADS(l, nthr) {   // inter-vehicle rows: (first pass: assemble,) column maxima to the timestep, row factor
+        for (int r = l; r < (int)rcap; r += nthr) {
+          const int pl_ = r >> 2, q = r & 3;
+          double a, bb, cy, e_acc;
+          int tp;
+          if (pass == 0) {
+            // calcInterVehicleConstraint :1097-1129: row = [a, b, a*Dx + b*Dy] on (x,y,yaw)_t, upper bound
+            // -(c + (a*Ex + b*Ey)), lower bound -inf
+            const PlaneDev& pd = planes[pl_];
+            tp = (int)pd.t;
+            a = pd.c[3 * q];
+            bb = pd.c[3 * q + 1];
+            const double cc = pd.c[3 * q + 2];
+            const bool front = q < 2;
+            const double Dx = front ? SU(14, tp) : SU(16, tp), Dy = front ? SU(15, tp) : SU(17, tp);
+            const double Ex = front ? SU(18, tp) : SU(20, tp), Ey = front ? SU(19, tp) : SU(21, tp);
+            cy = a * Dx + bb * Dy;
+            rz(r, 4, R_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
+            e_acc = 1.0;
+            if (rz_lds && q == 0) sh.fx[(size_t)5 * (size_t)rcap + (unsigned)pl_] = (double)tp;
+          } else {
+            tp = rz_time(pl_);
+            a = rz(r, 0, R_CA);
+            bb = rz(r, 1, R_CB);
+            cy = rz(r, 2, R_CY);
+            e_acc = rz(r, 3, R_E);
+          }
+          const double fa = fabs(a), fb = fabs(bb), fc = fabs(cy);
+          lds_max_nonneg(&SU(10, tp), fa);
+          lds_max_nonneg(&SU(11, tp), fb);
+          lds_max_nonneg(&SU(12, tp), fc);
+          const double rn = nmax(nmax(fa, fb), fc);
+          const double et = 1.0 / sqrt(limit_norm(rn));
+          rz(r, 0, R_CA) = a * et;
+          rz(r, 1, R_CB) = bb * et;
+          rz(r, 2, R_CY) = cy * et;
+          rz(r, 3, R_E) = e_acc * et;
+        }
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
@@ -671,42 +717,32 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         double* Dt = S.b;                    // scratch: per-column factor of this pass
         double* Et = S.z;                    // scratch: per-row factor of this pass
         if (t > 0) {
-          CSDO_FOR(k, 4, { cn_[k] = SH(carry, k, t - 1); });
-          cn_[4] = SH(carry, 4, t - 1);
+          CSDO_FOR(k, 4, { cn_[k] = SU(k, t - 1); });
+          cn_[4] = SU(4, t - 1);
         }
-        cn_[4] = dmax(cn_[4], dmax(fabs(S.Pvv), fabs(S.Pvn)));
-        cn_[5] = dmax(cn_[5], fabs(S.Pww));
+        cn_[4] = nmax(cn_[4], nmax(fabs(S.Pvv), fabs(S.Pvn)));
+        cn_[5] = nmax(cn_[5], fabs(S.Pww));
         CSDO_FOR(i, NROW, {
           double rn = 0.0;
           if (S.act & (1u << i)) {
             CSDO_FOR(s, 3, {
               if constexpr (row_col(i, s) >= 0) {
                 const double a = fabs(S.c[i][s]);
-                rn = dmax(rn, a);
-                cn_[row_col(i, s)] = dmax(cn_[row_col(i, s)], a);
+                rn = nmax(rn, a);
+                cn_[row_col(i, s)] = nmax(cn_[row_col(i, s)], a);
               }
             });
-            if constexpr (i < 4) rn = dmax(rn, fabs(S.cn[i]));
+            if constexpr (i < 4) rn = nmax(rn, fabs(S.cn[i]));
           }
-          Et[i] = 1.0 / sqrt(limit_scaling(rn));
+          Et[i] = 1.0 / sqrt(limit_norm(rn));
         });
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          cn_[0] = dmax(cn_[0], fabs(rz(r, 0, R_CA)));
-          cn_[1] = dmax(cn_[1], fabs(rz(r, 1, R_CB)));
-          cn_[2] = dmax(cn_[2], fabs(rz(r, 2, R_CY)));
-        }
-        CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_scaling(cn_[j])) : 1.0; });
-        // inter rows only touch own columns: scale them now
-        for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-          const double a = rz(r, 0, R_CA), bb = rz(r, 1, R_CB), cy = rz(r, 2, R_CY);
-          const double rn = dmax(dmax(fabs(a), fabs(bb)), fabs(cy));
-          const double et = 1.0 / sqrt(limit_scaling(rn));
-          rz(r, 0, R_CA) = (a * et) * Dt[0];
-          rz(r, 1, R_CB) = (bb * et) * Dt[1];
-          rz(r, 2, R_CY) = (cy * et) * Dt[2];
-          rz(r, 3, R_E) = rz(r, 3, R_E) * et;
-        }
-        CSDO_FOR(k, 5, { SH(carry2, k, t) = Dt[k]; });
+        CSDO_FOR(k, 3, {   // the timestep's inter-vehicle rows; cleared for the next pass
+          cn_[k] = nmax(cn_[k], SU(10 + k, t));
+          SU(10 + k, t) = 0.0;
+        });
+        CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_norm(cn_[j])) : 1.0; });
+        CSDO_FOR(k, 5, { SU(5 + k, t) = Dt[k]; });
+        if (t == 0) sh.bcast[30 + ((pass + 1) & 1)] = 0.0;   // the other pass parity's cost-scaling flag
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
@@ -714,40 +750,53 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double* Dt = S.b;
         const double* Et = S.z;
         double Dn[5] = {1, 1, 1, 1, 1};
-        if (t < Nm) CSDO_FOR(k, 5, { Dn[k] = SH(carry2, k, t + 1); });
+        if (t < Nm) CSDO_FOR(k, 5, { Dn[k] = SU(5 + k, t + 1); });
         CSDO_FOR(i, NROW, {
           CSDO_FOR(s, 3, {
             if constexpr (row_col(i, s) >= 0) S.c[i][s] = (S.c[i][s] * Et[i]) * Dt[row_col(i, s)];
           });
           if constexpr (i < 4) S.cn[i] = (S.cn[i] * Et[i]) * Dn[i];
-          CD(C_E + i, t) = CD(C_E + i, t) * Et[i];
+          SU(14 + i, t) = (pass == 0) ? Et[i] : SU(14 + i, t) * Et[i];
         });
         // scaled |P(v_{t-1}, v_t)| as its owner computes it
         double pvn_left = 0.0;
-        if (t > 0) pvn_left = (SH(carry, 4, t - 1) * SH(carry2, 4, t - 1)) * Dt[4];
+        if (t > 0) pvn_left = (SU(4, t - 1) * SU(9, t - 1)) * Dt[4];
         S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
         S.Pww = (S.Pww * Dt[5]) * Dt[5];
         S.Pvn = (S.Pvn * Dt[4]) * Dn[4];
-        CSDO_FOR(j, 6, { CD(C_D + j, t) = CD(C_D + j, t) * Dt[j]; });
+        CSDO_FOR(j, 6, { S.dsc[j] = S.dsc[j] * Dt[j]; });
         // cost normalisation: mean column norm of the scaled P
         double colsum = 0.0;
-        if (t < Nm) colsum = dmax(dmax(fabs(S.Pvv), fabs(S.Pvn)), pvn_left) + fabs(S.Pww);
-        const double part[1] = {colsum};
-        red_put<1>(sh, t, part);
+        if (t < Nm) colsum = nmax(nmax(fabs(S.Pvv), fabs(S.Pvn)), pvn_left) + fabs(S.Pww);
+        SU(13, t) = colsum;
+        // c_temp = max(sum / n_vars, 1) is 1 - P, c unchanged - unless the sum exceeds n_vars = 6 Nt - 2, which takes a lane
+        // above 5: only then is the sum formed (P's columns are equilibrated to ~1 by this very pass; never observed)
+        if (colsum > 5.0) sh.bcast[30 + (pass & 1)] = 1.0;
       }
-      double r[1];
-      red_fold<1, true>(sh, Nt, r);
-      double c_temp = r[0] / (double)n_vars;
-      c_temp = osqp_max(c_temp, limit_scaling(0.0));  // ||q||_inf = 0 -> 1 (q = 0, :196-197)
-      c_temp = limit_scaling(c_temp);
-      c_temp = uniform_f64(1.0 / c_temp);
-      CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
-        S.Pvv *= c_temp;
-        S.Pww *= c_temp;
-        S.Pvn *= c_temp;
+      CSDO_STHREADS(l, nthr) {   // inter-vehicle rows only touch the columns of their own timestep
+        for (int r = l; r < (int)rcap; r += nthr) {
+          const int tp = rz_time(r >> 2);
+          rz(r, 0, R_CA) = rz(r, 0, R_CA) * SU(5, tp);
+          rz(r, 1, R_CB) = rz(r, 1, R_CB) * SU(6, tp);
+          rz(r, 2, R_CY) = rz(r, 2, R_CY) * SU(7, tp);
+        }
       }
-      cscale = uniform_f64(cscale * c_temp);
+      CSDO_SYNC();
+      if (uniform_f64(sh.bcast[30 + (pass & 1)]) != 0.0) {
+        double r[1];
+        field_sum(sh, Nt, 13, r);
+        double c_temp = r[0] / (double)n_vars;
+        c_temp = osqp_max(c_temp, limit_scaling(0.0));  // ||q||_inf = 0 -> 1 (q = 0, :196-197)
+        c_temp = limit_scaling(c_temp);
+        c_temp = uniform_f64(1.0 / c_temp);
+        CSDO_LANES(t) {
+          LaneState& S = CSDO_LS(t);
+          S.Pvv *= c_temp;
+          S.Pww *= c_temp;
+          S.Pvn *= c_temp;
+        }
+        cscale = uniform_f64(cscale * c_temp);
+      }
     }
     const double cinv = uniform_f64(1.0 / cscale);
 
@@ -757,9 +806,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       unsigned eq = 0, loose = 0;
+      CSDO_FOR(i, NROW, {
+        S.lo[i] = WS(W_LO + i, t);
+        S.hi[i] = WS(W_HI + i, t);
+      });
       CSDO_FOR(i, NROW, {   // (every row: E = 1 and zero bounds where the row does not exist; classes only for those that do)
         {
-          const double Ei = CD(C_E + i, t);
+          const double Ei = SU(14 + i, t);
+          CD(C_E + i, t) = Ei;
           S.lo[i] = Ei * S.lo[i];
           S.hi[i] = Ei * S.hi[i];
           if (S.lo[i] < -OSQP_INFTY * MIN_SCALING && S.hi[i] > OSQP_INFTY * MIN_SCALING) loose |= 1u << i;
@@ -773,16 +827,35 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       WS(W_ACT, t) = (double)S.act;
       WS(W_EQ, t) = (double)eq;
       WS(W_LOOSE, t) = (double)loose;
-      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) ROW(r, R_U) = rz(r, 3, R_E) * ROW(r, R_U);
       // osqp_warm_start_x: x <- Dinv x0
-      CSDO_FOR(j, 6, { S.x[j] = (1.0 / CD(C_D + j, t)) * CD(C_SOL0 + j, t); });
-      CSDO_FOR(k, 4, { SH(carry2, k, t) = S.x[k]; });
+      CSDO_FOR(j, 6, {
+        CD(C_D + j, t) = S.dsc[j];
+        S.x[j] = (1.0 / S.dsc[j]) * CD(C_SOL0 + j, t);
+      });
+      CSDO_FOR(k, 4, { SU(5 + k, t) = S.x[k]; });
     }
     CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {   // inter-vehicle rows: z <- A x, y <- 0; the master copy goes to the workspace
+      for (int r = l; r < (int)rcap; r += nthr) {
+        const int tp = rz_time(r >> 2);
+        const double a = rz(r, 0, R_CA), bb = rz(r, 1, R_CB), cy = rz(r, 2, R_CY), e_acc = rz(r, 3, R_E);
+        ROW(r, R_Z) = (a * SU(5, tp) + bb * SU(6, tp)) + cy * SU(7, tp);
+        ROW(r, R_Y) = 0.0;
+        ROW(r, R_DY) = 0.0;
+        const double u_scaled = e_acc * rz(r, 4, R_U);
+        ROW(r, R_U) = u_scaled;
+        if (rz_lds) {   // publish what the set-up stages kept in LDS
+          ROW(r, R_CA) = a;
+          ROW(r, R_CB) = bb;
+          ROW(r, R_CY) = cy;
+          ROW(r, R_E) = e_acc;
+        }
+      }
+    }
     CSDO_LANES(t) {  // z <- A x, y <- 0
       LaneState& S = CSDO_LS(t);
       double xn[4] = {0, 0, 0, 0};
-      if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(carry2, k, t + 1); });
+      if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SU(5 + k, t + 1); });
       double Ax[NROW];
       rows_times_x(S, S.x, xn, Ax);
       CSDO_FOR(i, NROW, {
@@ -790,18 +863,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         S.y[i] = 0.0;
         CD(C_DY + i, t) = 0.0;
       });
-      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-        const double a = rz(r, 0, R_CA), bb = rz(r, 1, R_CB), cy = rz(r, 2, R_CY);
-        ROW(r, R_Z) = (a * S.x[0] + bb * S.x[1]) + cy * S.x[2];
-        ROW(r, R_Y) = 0.0;
-        ROW(r, R_DY) = 0.0;
-        if (rz_lds) {   // publish what the set-up stages kept in LDS
-          ROW(r, R_CA) = a;
-          ROW(r, R_CB) = bb;
-          ROW(r, R_CY) = cy;
-          ROW(r, R_E) = rz(r, 3, R_E);
-        }
-      }
       // the set-up stage worked in registers; publish the master copy for the cold phases and for load_hot
       CSDO_FOR(i, NROW, {
         CSDO_FOR(s, 3, {
@@ -1752,6 +1813,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 }
 
 #undef SH
+#undef SU
 #undef SX
 #undef FE
 #undef ER

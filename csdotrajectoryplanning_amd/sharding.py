@@ -16,16 +16,48 @@ def shard_bounds(n_items, world_size):
     return bounds
 
 
+def shard_bounds_weighted(weights, world_size):
+    """Contiguous blocks [lo, hi) per rank of near-equal total WEIGHT: block r ends where the running sum first reaches
+    (r + 1) / world_size of the total ("balance by Nt (13 + 4 K_a / Nt) if K is skewed"; here the weights are the
+    launcher's own work estimate, csdo_dsqp_estimate_work).  Agents take 3-6x the median time when their initial guess sits in
+    tight spots, so equal COUNTS leave the ranks unequal; every rank keeps at least one item while there are enough."""
+    w = np.asarray(weights, dtype=np.float64)
+    n = len(w)
+    if n == 0 or world_size <= 0:
+        return [(0, 0)] * max(world_size, 0)
+    cum = np.cumsum(np.maximum(w, 0.0))
+    total = float(cum[-1])
+    if not total > 0.0:
+        return shard_bounds(n, world_size)
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        i = int(np.searchsorted(cum, target, side="left")) + 1        # first prefix whose sum reaches the target
+        # take the closer of the two candidate cuts, stay monotone, leave enough items for the ranks behind
+        if i - 1 > cuts[-1] and abs(cum[i - 2] - target) <= abs(cum[i - 1] - target):
+            i -= 1
+        i = max(i, cuts[-1] + (1 if n - cuts[-1] > world_size - r else 0))
+        i = min(i, n - min(world_size - r, n - cuts[-1]) if n - cuts[-1] > world_size - r else n)
+        cuts.append(min(max(i, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
 def shard_world(world, rank, world_size):
     lo, hi = shard_bounds(world.Na, world_size)[rank]
     return (world.subset(lo, hi) if hi > lo else None), (lo, hi)
 
 
-def shard_batch_plan(world_sizes, rank, world_size):
+def shard_batch_plan(world_sizes, rank, world_size, weights=None):
     """Contiguous block of the batch's agents (worlds concatenated in order) owned by `rank`: a list of
-    (world index, lo, hi) with agents [lo, hi) of that world; only worlds that overlap the block appear."""
+    (world index, lo, hi) with agents [lo, hi) of that world; only worlds that overlap the block appear.
+    weights: per-agent work estimates (len = sum(world_sizes)): blocks of equal work instead of equal agent count."""
     total = int(sum(world_sizes))
-    lo, hi = shard_bounds(total, world_size)[rank]
+    if weights is not None:
+        assert len(weights) == total
+        lo, hi = shard_bounds_weighted(weights, world_size)[rank]
+    else:
+        lo, hi = shard_bounds(total, world_size)[rank]
     plan, first = [], 0
     for w, n in enumerate(world_sizes):
         a, b = max(lo, first), min(hi, first + n)

@@ -111,6 +111,30 @@ class DsqpHandle:
         lib().csdo_bridge_free(C.byref(bo))
         return out
 
+    def interpolate_and_planes_batch(self, items, veh, parm):
+        """csdo_preprocess_device_batch: items = [(states, actions, path_off, goals, dimx, dimy, obstacles), ...], one per world;
+        returns [(World, pairs, initial_inter_legal), ...] - per world what interpolate_and_planes returns."""
+        n = len(items)
+        keep = []
+        st_p, ac_p, po_p, g_p = (abi.c_double_p * n)(), (abi.c_int32_p * n)(), (abi.c_int32_p * n)(), (abi.c_double_p * n)()
+        na = np.zeros(n, np.int32)
+        for k, (st, ac, po, G, _, _, _) in enumerate(items):
+            st = np.ascontiguousarray(st, dtype=np.float64)
+            ac = np.ascontiguousarray(ac, dtype=np.int32)
+            po = np.ascontiguousarray(po, dtype=np.int32)
+            G = np.ascontiguousarray(G, dtype=np.float64)
+            keep.append((st, ac, po, G))
+            st_p[k], ac_p[k], po_p[k], g_p[k] = abi.as_double_p(st), abi.as_int32_p(ac), abi.as_int32_p(po), abi.as_double_p(G)
+            na[k] = len(po) - 1
+        outs = (abi.BridgeOut * n)()
+        check(lib().csdo_preprocess_device_batch(self._h, n, st_p, ac_p, po_p, abi.as_int32_p(na), g_p, C.byref(veh),
+                                                 C.byref(parm), outs), "csdo_preprocess_device_batch")
+        res = []
+        for k, it in enumerate(items):
+            res.append(bridge_to_world(outs[k], it[4], it[5], it[6], veh, parm))
+            lib().csdo_bridge_free(C.byref(outs[k]))
+        return res
+
     def validate(self, solutions, veh, obstacles=None, dimx=0.0, dimy=0.0, margin=0.0, frames_per_move=None):
         """Trajectory validator on this GPU (csdo_validate; with frames_per_move = S >= 1 csdo_validate_frames: the frames
         of the authors' animation, indices in the report are frames); returns a results.ValidationReport."""
@@ -175,6 +199,14 @@ class SolverDSQP:
 
     def get_initial_static_legal(self):
         return bool(self._sol.initial_static_legal)
+
+
+def estimate_work(worlds):
+    """csdo_dsqp_estimate_work: the launcher's relative work estimate of every agent of `worlds`, in order (host code)."""
+    probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
+    est = np.zeros(int(sum(w.Na for w in worlds)))
+    check(lib().csdo_dsqp_estimate_work(probs, len(worlds), abi.as_double_p(est)), "csdo_dsqp_estimate_work")
+    return est
 
 
 def interpolate_and_planes(states, actions, path_off, goals, veh, parm, dimx, dimy, obstacles):

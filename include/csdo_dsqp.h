@@ -12,6 +12,11 @@
  *   csdo_preprocess        <->  InterpolateInitalGuess + findNeighborPairsByTrustRegion + calcEqualInterPlanes
  *                               sqp/inter_agent_cons.h:11-13,40-45,69-73; call sites csdo.cc:116-129
  *   csdo_preprocess_device <->  the same three calls with the pair search and plane generation on the device
+ *   csdo_preprocess_device_batch  the same for several worlds in one call (the loop over instances of the authors' sweep,
+ *                               scripts/test_through_benchmark.sh:47,91-97, is the batch axis of this backend)
+ *   csdo_dsqp_estimate_work <-> (extension) the relative per-agent work estimate the launcher orders agents by; shards
+ *                               a batch over GPUs by work instead of by agent count (dsqp_solver.cc:1198-1220 is the loop
+ *                               that shards)
  *   csdo_front_end_plan    <->  PBS::solve over the spatiotemporal hybrid A* (the "CS" half of CSDO)
  *                               pbs/PBS.cc:28-66,665-719, hybrid_a_star/hybrid_astar.h:91-207, environment.h:128-521;
  *                               call site csdo.cc:93-110.  Host code: the search is pointer-chasing, branchy and serial
@@ -138,16 +143,20 @@ double csdo_dsqp_last_kernel_seconds(csdo_handle h);
 /* Host seconds of the last upload / download: out[0] packing the worlds, out[1] staging into page-locked memory,
  * out[2] H2D copies (+ first-call device allocation), out[3] D2H copies, out[4] scattering into the caller's buffers. */
 int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]);
-/* How the uploaded batch is launched: agents are grouped by kernel class (workgroup size by horizon; LDS residency by
- * working set: 0 = coupling blocks, pivot inverses and bounds all in LDS, 1 = bounds read from the L2-resident workspace,
- * 2 = pivot inverses too, 3 = only the exchange vectors in LDS); every group is a set of persistent workgroups that take
- * its agents off a queue ordered heaviest first, and the groups run concurrently.  Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
+/* How the uploaded batch is launched: agents are grouped by kernel class - workgroup size by horizon (256 threads and two
+ * workgroups per CU for Nt <= 128 when the working set fits 80 KB, 512 up to Nt = 256, 1024 beyond) and LDS residency by
+ * working set: 0 = exchange vectors, bounds and the third of the factor that is not in registers in LDS (per agent also
+ * the inter-vehicle rows' duals / slacks, where they fit); 1 = that part of the factor read from the workspace instead
+ * (512-thread class only); 3 = the 1024-thread class: exchange vectors only.  Every group is a set of persistent
+ * workgroups that take its agents off a queue ordered heaviest first, and the groups run concurrently.  `lds_bytes` may
+ * be the full 80 / 160 KB of the class: what the agents do not need caches the planes' read-only coefficients.
+ * Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
  * the duration of the group's kernel in the last csdo_dsqp_run.  No reference counterpart (the reference loops over
  * agents serially, sqp/dsqp_solver.cc:1198-1205). */
 typedef struct csdo_launch_group {
   int32_t n_agents;
   int32_t threads;             /* per workgroup: 256, 512 or 1024 */
-  int32_t residency_mode;      /* 0 .. 3, see above */
+  int32_t residency_mode;      /* 0, 1 or 3, see above */
   int32_t max_nt;
   int64_t lds_bytes;
   double seconds;
@@ -155,9 +164,14 @@ typedef struct csdo_launch_group {
 int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t cap);
 /* Which launch group every agent of the uploaded batch belongs to, in upload order (world 0's agents, world 1's, ...). */
 int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents);
-/* Testing / tuning knob: from the next upload on, no agent uses a residency mode below `mode` (0 restores the
- * automatic choice).  Results do not depend on the mode, only the speed does. */
+/* Testing / tuning knob, from the next upload on (0 restores the automatic choice): 1 keeps the inter-vehicle rows' duals
+ * and slacks in the workspace for every agent (the mode stays 0); >= 2 additionally puts the 512-thread class into mode 1.
+ * The 256- and 1024-thread classes have one mode each.  Results do not depend on it, only the speed does. */
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
+/* The launcher's relative work estimate per agent (the quantity the launch order and the CU shares of the groups come
+ * from: horizon, plane count and how much of the initial guess sits in tight spots), in upload order; host code, no GPU
+ * needed.  For sharding a batch over GPUs by work instead of by agent count. */
+int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double* est /* [sum Na] */);
 /* Device pointer to the packed solutions of the last run ([sum Na][Nt_stride][6] doubles) for collectives. */
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles);
 
@@ -181,6 +195,13 @@ void csdo_bridge_free(csdo_bridge_out* out);
  * (t, i, j) order); interpolation and CSR assembly stay on the host.  Outputs are bit-identical to csdo_preprocess. */
 int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                            const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out);
+/* The device bridge for n_worlds worlds in one call (every argument of csdo_preprocess_device as an array over the worlds;
+ * veh and parm are shared): one copy up, the kernels of all worlds back to back, two host-device synchronisations in all
+ * instead of four per world.  outs[w] equals what csdo_preprocess returns for world w, bit for bit; on an error every
+ * outs[w] is released and zeroed. */
+int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* const* states, const int32_t* const* actions,
+                                 const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
+                                 const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs /* [n_worlds] */);
 
 /* Front end (host): priority-based search, each agent planned by a spatiotemporal hybrid A* that yields to the agents
  * ranked above it.  starts / goals [Na][3] = x, y, yaw.  On success (status 1) the paths come back in exactly the layout

@@ -115,3 +115,47 @@ def test_weak_scaling_job_gives_every_rank_one_copy():
             assert 0 <= lo < hi <= sizes1[w]
             seen += hi - lo
     assert seen == 1500
+
+
+def test_blocks_of_equal_estimated_work():
+    """sharding.shard_bounds_weighted / shard_batch_plan(weights=): contiguous, complete, and balanced by weight."""
+    from csdotrajectoryplanning_amd.sharding import shard_batch_plan, shard_bounds, shard_bounds_weighted
+    rng = np.random.default_rng(5)
+    for n, ws in [(50, 8), (3000, 8), (1024, 4), (10, 3), (8, 8), (3, 4), (1, 2)]:
+        w = rng.lognormal(0.0, 1.0, n)
+        b = shard_bounds_weighted(w, ws)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
+        if n >= 8 * ws:
+            loads = np.array([w[lo:hi].sum() for lo, hi in b])
+            assert loads.max() <= 1.1 * loads.mean() + w.max()
+    assert shard_bounds_weighted(np.ones(50), 8) == shard_bounds_weighted(np.full(50, 3.5), 8)
+    assert [hi - lo for lo, hi in shard_bounds_weighted(np.ones(48), 8)] == [6] * 8
+    assert shard_bounds_weighted(np.zeros(10), 2) == shard_bounds(10, 2)
+    # the plan cuts through worlds where the weights say so
+    plan0 = shard_batch_plan([3, 4], 0, 2, weights=[1, 1, 1, 1, 1, 1, 6])
+    plan1 = shard_batch_plan([3, 4], 1, 2, weights=[1, 1, 1, 1, 1, 1, 6])
+    assert plan0 == [(0, 0, 3), (1, 0, 3)] and plan1 == [(1, 3, 4)]
+
+
+def test_map100_set_shards_by_the_launchers_work_estimate():
+    """bench.py --gpus 8: the map100 set (3000 agents) cut into 8 blocks by csdo_dsqp_estimate_work (the library's own per-agent
+    estimate; host code, no GPU): the heaviest rank's estimated work stays within 1.1x of the mean, which equal agent counts
+    do not guarantee, and a weak-scaling job of 8 copies gives every rank about one copy's worth."""
+    from csdotrajectoryplanning_amd import sharding, workloads
+    from csdotrajectoryplanning_amd.solver import estimate_work
+    worlds = [w for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs("map100"), min(os.cpu_count() or 8, 16))]
+    est = estimate_work(worlds)
+    assert est.shape == (3000,) and np.all(est > 0) and est.max() / np.median(est) > 2.0     # skewed: that is the point
+    for ws in (2, 4, 8):
+        loads = np.array([est[lo:hi].sum() for lo, hi in sharding.shard_bounds_weighted(est, ws)])
+        assert loads.max() <= 1.1 * loads.mean(), (ws, loads / loads.mean())
+        seen = 0
+        for r in range(ws):
+            for w, lo, hi in sharding.shard_batch_plan([x.Na for x in worlds], r, ws, weights=est):
+                seen += hi - lo
+        assert seen == 3000
+    est8 = np.tile(est, 8)
+    loads = np.array([est8[lo:hi].sum() for lo, hi in sharding.shard_bounds_weighted(est8, 8)])
+    assert loads.max() <= 1.02 * loads.mean()
+    # estimates of a sub-batch equal the slice of the whole batch's (per agent, no cross-talk)
+    assert np.array_equal(estimate_work(worlds[3:5]), est[150:250])

@@ -541,10 +541,13 @@ def main():
                                    "single_core_value": float(so1.admm_iters.sum()) / t_one,
                                    "do_phase_ms_single_instance_one_thread_per_agent": t_inst * 1e3,
                                    "do_phase_ms_single_instance_single_core": t_one * 1e3}
-        print(json.dumps(out))
+        line = json.dumps(out)
     h.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:       # the ONE line, after everything that may write to stdout on its own (RCCL prints a banner)
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -541,12 +541,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 16..23: factor sub-phases
   long long prof_last = (long long)__builtin_amdgcn_s_memtime();
   int prof_cur = 0;
+  long long sub_acc[6] = {0, 0, 0, 0, 0, 0}, sub_last = 0;   // free sub-timers of whatever is under the microscope: prof[40..45]
+#define CSDO_SUB_RESET() do { if (threadIdx.x == 0) sub_last = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define CSDO_SUB(k) do { if (threadIdx.x == 0) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); sub_acc[k] += n_ - sub_last; sub_last = n_; } } while (0)
   long long lvl_fwd = 0, lvl_bwd = 0;  // solver lane t == h: cycles inside its own elimination block
 #define CSDO_LVL_BEGIN() const long long lvl_t0 = (long long)__builtin_amdgcn_s_memtime()
 #define CSDO_LVL_END(acc) acc += (long long)__builtin_amdgcn_s_memtime() - lvl_t0
 #else
 #define CSDO_LVL_BEGIN() ((void)0)
 #define CSDO_LVL_END(acc) ((void)0)
+#define CSDO_SUB_RESET() ((void)0)
+#define CSDO_SUB(k) ((void)0)
 #endif
 
 #define ROW(r, f) (rows + (int64_t)(f) * rcap)[(unsigned)(r)]
@@ -666,6 +671,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_MARK("ruiz");
     double cscale = 1.0;
     for (int pass = 0; pass < P.scaling_passes; ++pass) {
+      CSDO_SUB_RESET();
       CSDO_LANES(t) {  // hand |cn| and |Pvn| to t+1
         LaneState& S = CSDO_LS(t);
         CSDO_FOR(k, 4, { SU(k, t) = fabs(S.cn[k]); });
@@ -711,6 +717,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
       }
       CSDO_SYNC();
+      CSDO_SUB(0);
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
         double cn_[6] = {0, 0, 0, 0, 0, 0};  // column norms of [P; A]
@@ -745,6 +752,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         if (t == 0) sh.bcast[30 + ((pass + 1) & 1)] = 0.0;   // the other pass parity's cost-scaling flag
       }
       CSDO_SYNC();
+      CSDO_SUB(1);
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
         const double* Dt = S.b;
@@ -782,6 +790,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
       }
       CSDO_SYNC();
+      CSDO_SUB(2);
       if (uniform_f64(sh.bcast[30 + (pass & 1)]) != 0.0) {
         double r[1];
         field_sum(sh, Nt, 13, r);
@@ -1220,6 +1229,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         SH(carry, 5, t) = WS(W_P + 2, t);
       }
       CSDO_SYNC();
+      CSDO_SUB_RESET();
       CSDO_LANES(t) {
         // the iterate and the coefficients come from the workspace (the block has just written x, y, z back), into
         // temporaries of this phase: the row lanes' hot register cache is dead here
@@ -1314,7 +1324,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         });
         red_put<12>(sh, t, p);
       }
+      CSDO_SUB(3);
       red_fold<12, false>(sh, Nt, nrm);
+      CSDO_SUB(4);
       info_valid = true;
     };
 
@@ -1430,6 +1442,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_FOR(j, 6, { SH(rhs, j, t) = r6[j]; });
         CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
       };
+      CSDO_SUB_RESET();
       CSDO_LANES(t) {  // load the row-lane cache, in stages: with every load of it in flight at once (some 90 doubles) this
         // is the row role's register peak, and what the allocator spills for it stays spilled in the iterations
         LaneState& S = CSDO_LS(t);
@@ -1495,6 +1508,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_STHREADS(l, nthr) { plane_pass(std::false_type{}, std::false_type{}, std::false_type{}, l, nthr, rho); }
       }
       CSDO_SYNC();
+      CSDO_SUB(5);
       auto iteration = [&](auto keep_c) __attribute__((always_inline)) {
         constexpr bool keep_dy = decltype(keep_c)::value;   // only the last iteration of a block records delta_y
         // ---- rhs of the reduced system: the solver lane adds the kinematic share of t-1 and its planes' shares to what
@@ -1792,6 +1806,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   if (threadIdx.x == 0 && B.prof) {
     for (int k = 0; k < 16; ++k) B.prof[(int64_t)agent * 48 + k] = prof_acc[k];
     for (int k = 16; k < 24; ++k) B.prof[(int64_t)agent * 48 + 8 + k] = prof_acc[k];
+    for (int k = 0; k < 6; ++k) B.prof[(int64_t)agent * 48 + 40 + k] = sub_acc[k];
   }
   if constexpr (ROLE == ROLE_SOLVER) {
     const int ts = (int)threadIdx.x - (int)(blockDim.x >> 1);

@@ -32,6 +32,9 @@ for label, sel in (("all agents", it >= 0), ("short agents (< 1000 iterations)",
     print("   cycles per SQP iteration: " + "  ".join("%s %.0fk" % (NAMES[i], p[i] / max(sq[sel].sum(), 1) / 1e3) for i in (1, 2, 3, 4, 5, 10, 11, 12)))
     fsub = ph[sel][:, 24:28].sum(0).astype(float)    # factor sub-phases (slots 16..19 of the kernel's timers)
     print("   factor, cycles per SQP iteration: assembly %.0fk  levels: elimination %.0fk + absorption %.0fk  tail inversion %.0fk  (the factor column above counts only the rest)" % tuple(fsub[[0, 3, 1, 2]] / max(sq[sel].sum(), 1) / 1e3))
+    subs = ph[sel][:, 40:46].sum(0).astype(float) / max(sq[sel].sum(), 1) / 1e3
+    print("   sub-timers, k cycles per SQP iteration: ruiz phase 1 %.0f  phase 2 %.0f  phase 3 %.0f | info lane loop %.0f  info fold %.0f | "
+          "block load %.0f" % tuple(subs))
     n_it = max(it[sel].sum(), 1)
     print("   cycles per ADMM iteration: " + "  ".join("%s %.0f" % (NAMES[i], p[i] / n_it) for i in (6, 7, 13, 8, 14, 9)) +
           "  | iteration total %.0f" % (sum(p[i] for i in (6, 7, 13, 8, 14, 9)) / n_it))

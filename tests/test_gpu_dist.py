@@ -57,7 +57,9 @@ def test_bench_force_dist_line():
                           "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--skip-single-instance"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "ONE-rank nccl" in d["config"]["collective"]
     assert d["config"]["shard_balance"]["estimated_work_max_over_mean"] == 1.0
     assert d["value"] > 0 and d["config"]["agents_rank0"] == 300

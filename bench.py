@@ -8,6 +8,8 @@ its ADMM QPs) over one batch of worlds whose inputs are already resident in HBM.
                       3000 agents in ONE batch
            map50      (configs[1]) the 60 instances of map50by50/agents25/obstacle, 1500 agents
            synth1024  (configs[4]) 21 worlds (ex0..ex20 of the map100 set) truncated to 1024 agents
+           room50     benchmark/room/agents50 ex0..ex11: 238 obstacles per world (the obstacle-dense regime)
+           agents100  benchmark/map100by100/agents100/obstacle ex0..ex11: 100 vehicles per world (the plane-dense regime)
 N > 1 ranks (torch.distributed.run, one process per GPU, RCCL):
 Either way the agents of the job are SHARDED by sharding.shard_batch_plan: rank r owns one contiguous block of the job's
 concatenated agents (the reference's loop over agents is what shards, sqp/dsqp_solver.cc:1198-1220), builds only the worlds
@@ -119,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("map100", "map50", "synth1024"), default="map100")
+    ap.add_argument("--workload", choices=("map100", "map50", "synth1024", "room50", "agents100"), default="map100")
     ap.add_argument("--front", choices=("auto", "stand-in"), default="auto",
                     help="initial guesses: the front end's stored paths where it solves the instance (auto, default) or the "
                          "seeded stand-in for every instance (the round-1 workload, for like-for-like comparisons)")
@@ -442,6 +444,8 @@ def main():
         Nts = sorted(w.Nt for w in worlds)
         n_agents = int(sum(w.Na for w in worlds))
         wl_names = {"map100": "map100by100/agents50/obstacle set", "map50": "map50by50/agents25/obstacle set",
+                    "room50": "room/agents50 set, ex0..ex11 (238 wall obstacles per world)",
+                    "agents100": "map100by100/agents100/obstacle set, ex0..ex11 (100 vehicles per world)",
                     "synth1024": "synthetic 1024-agent stress batch (21 worlds = ex0..ex20 of the map100by100/agents50/"
                                  "obstacle set, truncated to 1024 agents)"}
         out = {

@@ -70,7 +70,8 @@ class FrontEndParm(C.Structure):
     """csdo_front_end_parm (include/csdo_dsqp.h)."""
     _fields_ = [("penalty_turning", C.c_double), ("penalty_reversing", C.c_double), ("penalty_cod", C.c_double),
                 ("map_resolution", C.c_double), ("max_closed_set_size", C.c_double), ("time_limit_s", C.c_double),
-                ("node_limit", C.c_int32), ("rand_seed", C.c_uint32)]
+                ("node_limit", C.c_int32), ("rand_seed", C.c_uint32), ("keep_off_lower_goals", C.c_int32),
+                ("_reserved", C.c_int32)]
 
 
 class Paths(C.Structure):

@@ -13,6 +13,12 @@
 //                                     tried on every pop with the reference's random range test (rand() % 10 + 1 after
 //                                     srand(0), csdo.cc:93; here a generator owned by the call, so that the entry is re-entrant)
 //   common/motion_planning.h:140-199  rectangle SAT between vehicles (float), inflated-obstacle test in the vehicle frame
+// Deliberate differences from the reference's rule set: (1) a Reeds-Shepp shot whose parked end pose a higher agent would
+// hit later is refused; (2) csdo_front_end_parm::keep_off_lower_goals (default on): poses at t >= 1 that overlap the goal
+// rectangle of an agent NOT ranked above the planning one are invalid - in the root node agent 0 therefore treats every other
+// goal as an obstacle - and (3) with that rule an agent whose start is boxed in by such goals is planned alone in the root
+// (make_root) and left to the priorities.  The reference has none of the three (environment.h:350-392, PBS.cc:665-719); with
+// (2) off, (3) never triggers.
 // Exact path equality with the reference is not attainable (heap tie-breaking, OMPL internals, unordered_set order) and
 // not claimed; the tests check what PBS itself validates: every step is a motion primitive, no two rectangles overlap at
 // equal times, no obstacle is touched, every path ends at its goal.
@@ -42,6 +48,7 @@ namespace {
 using clk = std::chrono::steady_clock;
 
 struct Consts {   // Constants:: of the reference, float members as there (common/motion_planning.cc:54-109)
+  bool keepOffLowerGoals;   // csdo_front_end_parm::keep_off_lower_goals (not in the reference)
   float r, deltat, penaltyTurning, penaltyReversing, penaltyCOD, mapResolution, xyResolution, yawResolution, maxClosed;
   float carWidth, LF, LB, f2x, r2x, rv;
   double dx[6], dy[6], dyaw[6];
@@ -58,6 +65,7 @@ Consts make_consts(const csdo_vehicle& v, const csdo_front_end_parm& p) {
   c.xyResolution = c.r * c.deltat;
   c.yawResolution = c.deltat;
   c.maxClosed = (float)p.max_closed_set_size;
+  c.keepOffLowerGoals = p.keep_off_lower_goals != 0;
   c.carWidth = (float)v.car_width;
   c.LF = (float)v.LF;
   c.LB = (float)v.LB;
@@ -143,8 +151,9 @@ class LowLevel {
       parked_.emplace(p->states.back().t, p->states.back());   // stays at its last pose from then on
     }
     lower_goals_.clear();
-    for (int a = 0; a < (int)goals_.size(); ++a)   // never drive through the goal of an agent that has to yield to us
-      if (a != agent_ && !higher.count(a)) lower_goals_.push_back(goals_[a]);
+    if (C.keepOffLowerGoals)   // (not a rule of the reference: environment.h:350-392) never drive through the goal of an agent that has to yield to us
+      for (int a = 0; a < (int)goals_.size(); ++a)
+        if (a != agent_ && !higher.count(a)) lower_goals_.push_back(goals_[a]);
     return search(start, deadline);
   }
 
@@ -721,6 +730,8 @@ void csdo_front_end_parm_default(csdo_front_end_parm* p) {   // config.yaml of t
   p->time_limit_s = 20.0;
   p->node_limit = 0;
   p->rand_seed = 0;
+  p->keep_off_lower_goals = 1;
+  p->_reserved = 0;
 }
 int csdo_front_end_plan(const double* starts, const double* goals, int32_t Na, double dimx, double dimy,
                         const double* obstacles, int32_t n_obs, const csdo_vehicle* veh, const csdo_front_end_parm* parm,

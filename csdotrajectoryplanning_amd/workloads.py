@@ -120,7 +120,14 @@ def synthetic_1024(veh=None, parm=None, seed_offset=0, n_agents=SYNTH1024_AGENTS
     return worlds, infos
 
 
-WORKLOADS = ("map100", "map50", "synth1024")
+WORKLOADS = ("map100", "map50", "synth1024", "room50", "agents100")
+# The regimes the two BASELINE sets do not reach (SURVEY 8 sizes): `room50` = benchmark/room/agents50 (238 obstacles of radius
+# 0.5 forming walls: five times the box work per point, obstacle staging in LDS), `agents100` = benchmark/map100by100/agents100/
+# obstacle (twice the vehicles, so about twice the separating planes per agent: the plane state of many agents no longer fits LDS
+# beside the rest; 2-tuple obstacles, radius from config.yaml's obsRadius).  Twelve instances each (ex0 .. ex11).
+ROOM_AGENTS50 = "room_agents50_ex{}.yaml"            # (benchmark/room/agents50/map_100by100_agents50_ex{}.yaml, renamed: the
+MAP100_AGENTS100 = "map_100by100_obst50_agents100_ex{}.yaml"   # name collides with the empty map100 family)
+EXTRA_SET_SIZE = 12
 
 
 def workload_jobs(name, n_instances=None, seed_offset=0, front="auto"):
@@ -133,6 +140,9 @@ def workload_jobs(name, n_instances=None, seed_offset=0, front="auto"):
         return [("map50", k, seed_offset, front) for k in range(n)]
     if name == "synth1024":
         return [("synth1024", k, seed_offset, front) for k in range(21)]
+    if name in ("room50", "agents100"):
+        n = EXTRA_SET_SIZE if n_instances is None else max(1, min(int(n_instances), EXTRA_SET_SIZE))
+        return [(name, k, seed_offset, front) for k in range(n)]
     raise ValueError("unknown workload %r (one of %s)" % (name, ", ".join(WORKLOADS)))
 
 
@@ -141,6 +151,10 @@ def build_job(job):
     kind, k, seed_offset, front = job
     if kind == "map50":
         return map50_world(k, seed_offset=seed_offset, front=front)
+    if kind == "room50":
+        return build_world(ROOM_AGENTS50.format(k), seed=k + seed_offset, front=front)
+    if kind == "agents100":
+        return build_world(MAP100_AGENTS100.format(k), seed=k + seed_offset, front=front)
     w, info = map100_world(k, seed_offset=seed_offset, front=front)
     if kind == "synth1024" and k == 20:
         left = SYNTH1024_AGENTS - 20 * 50
@@ -154,6 +168,8 @@ def job_agents(job):
     kind, k = job[0], job[1]
     if kind == "map50":
         return 25
+    if kind == "agents100":
+        return 100
     if kind == "synth1024" and k == 20:
         return SYNTH1024_AGENTS - 20 * 50
     return 50

@@ -216,6 +216,14 @@ typedef struct csdo_front_end_parm {
   double time_limit_s;                                      /* csdo.cc:100: 20 */
   int32_t node_limit;                                       /* high-level nodes; 0 = unlimited */
   uint32_t rand_seed;                                       /* csdo.cc:93: srand(0); seeds a generator owned by the call */
+  /* Two rules of this front end that the reference does NOT have (environment.h:350-392 tests the map, the obstacles, the
+   * higher agents at t and t +- 1 and the parked higher agents only; target conflicts are left to hasConflicts and the
+   * priorities).  1 (default): a vehicle never drives through the goal rectangle of an agent that has to yield to it, and an
+   * agent that is boxed in by such goals in the root node is planned alone and left to the priorities.  0: the reference's
+   * rule set.  The default solves 58 / 49 of the 60 / 60 map100 / map50 obstacle instances; profiles/r03_front_end_rules.json
+   * holds the counts for both settings. */
+  int32_t keep_off_lower_goals;
+  int32_t _reserved;
 } csdo_front_end_parm;
 typedef struct csdo_paths {
   int32_t Na, status;

@@ -61,7 +61,7 @@ def stats(d, dc, same):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=("map100", "map50", "synth1024"), default="map100")
+    ap.add_argument("--workload", choices=("map100", "map50", "synth1024", "room50", "agents100"), default="map100")
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 8, 32))
     ap.add_argument("--alt-oracle", default=os.path.join(ROOT, "oracle", "libcsdo_oracle_fma.so"))
     ap.add_argument("--no-emu", action="store_true")

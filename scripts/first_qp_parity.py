@@ -24,7 +24,7 @@ def with_max_iter(world, k):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", choices=("gpu", "emu"), default="gpu")
-    ap.add_argument("--workload", choices=("map100", "map50", "synth1024"), default="map100")
+    ap.add_argument("--workload", choices=("map100", "map50", "synth1024", "room50", "agents100"), default="map100")
     ap.add_argument("--instances", type=int, default=None)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--out", default=None)

@@ -6,7 +6,9 @@ unsolved.json and keep the seeded stand-in generator (synth.py).
 The search is deterministic for given limits (srand(seed) inside, no wall-clock decisions below the time limit); the time
 limit here is generous so that it never decides.  tests/test_front_end.py re-plans some instances and compares.
 
-usage: python tests/golden/make_front_end_paths.py [procs]
+usage: python tests/golden/make_front_end_paths.py [procs] [name filter (substring)] [--reference-rules OUT_DIR]
+  --reference-rules OUT_DIR: csdo_front_end_parm::keep_off_lower_goals = 0 (the reference's rule set), results into OUT_DIR
+  instead of tests/golden/front_end_paths (for the solved-count comparison in profiles/r03_front_end_rules.json)
 """
 import json
 import os
@@ -21,6 +23,7 @@ from csdotrajectoryplanning_amd import config, front_end, instance, workloads  #
 
 OUT = os.path.join(ROOT, "tests", "golden", "front_end_paths")
 TIME_LIMIT_S = 120.0
+KEEP_OFF = 1
 
 
 def run(name):
@@ -28,6 +31,7 @@ def run(name):
     inst = instance.load_instance(os.path.join(workloads.INSTANCE_DIR, name), obs_radius=veh.obs_radius)
     parm = front_end.default_parm()
     parm.time_limit_s = TIME_LIMIT_S
+    parm.keep_off_lower_goals = KEEP_OFF
     cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, parm)
     out = os.path.join(OUT, name.replace(".yaml", ".npz"))
     if cp is None:
@@ -39,15 +43,33 @@ def run(name):
     return name, (cp.seconds, cp.hl_expanded, cp.ll_expanded)
 
 
+def _init(out, keep_off):
+    global OUT, KEEP_OFF
+    OUT, KEEP_OFF = out, keep_off
+
+
 if __name__ == "__main__":
-    procs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    names = sorted(n for n in os.listdir(workloads.INSTANCE_DIR) if n.endswith(".yaml"))
+    args = [a for a in sys.argv[1:]]
+    if "--reference-rules" in args:
+        k = args.index("--reference-rules")
+        OUT, KEEP_OFF = args[k + 1], 0
+        del args[k:k + 2]
+    procs = int(args[0]) if len(args) > 0 else 4
+    pick = args[1] if len(args) > 1 else ""
+    names = sorted(n for n in os.listdir(workloads.INSTANCE_DIR) if n.endswith(".yaml") and pick in n)
     os.makedirs(OUT, exist_ok=True)
-    with ProcessPoolExecutor(procs) as ex:
+    with ProcessPoolExecutor(procs, initializer=_init, initargs=(OUT, KEEP_OFF)) as ex:
         res = list(ex.map(run, names))
     unsolved = sorted(n for n, r in res if r is None)
-    with open(os.path.join(OUT, "unsolved.json"), "w") as f:
-        json.dump({"time_limit_s": TIME_LIMIT_S, "unsolved": unsolved}, f, indent=1)
+    listed = {"time_limit_s": TIME_LIMIT_S, "unsolved": []}
+    path = os.path.join(OUT, "unsolved.json")
+    if pick and os.path.exists(path):          # a partial run keeps what it did not look at
+        with open(path) as f:
+            listed = json.load(f)
+        listed["unsolved"] = [n for n in listed["unsolved"] if pick not in n]
+    listed["unsolved"] = sorted(set(listed["unsolved"]) | set(unsolved))
+    with open(path, "w") as f:
+        json.dump(listed, f, indent=1)
     ok = [r for _, r in res if r is not None]
     print("solved %d of %d; search seconds mean %.2f max %.2f" % (len(ok), len(res), np.mean([r[0] for r in ok]),
                                                                    max(r[0] for r in ok)))

@@ -46,6 +46,10 @@ __device__ __forceinline__ int csdo_opaque(int v) {
   return v;
 }
 #define csdo_keep(v) csdo_opaque(v)   // a loaded value the compiler must not re-load (rematerialise) at its uses
+__device__ __forceinline__ double csdo_keep_f64(double v) {   // the same for a double: also keeps two loads from being merged
+  asm volatile("" : "+v"(v));
+  return v;
+}
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = csdo_opaque((int)threadIdx.x); t < Nt)
 // ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
 #define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
@@ -96,6 +100,7 @@ __device__ __forceinline__ int csdo_opaque(int v) {
 #endif
 #elif defined(CSDO_LANE_MODE_SERIAL)
 #define csdo_keep(v) (v)
+#define csdo_keep_f64(v) (v)
 #define CSDO_FN inline
 #define CSDO_NOINLINE inline
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)

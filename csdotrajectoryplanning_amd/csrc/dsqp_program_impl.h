@@ -1341,10 +1341,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // rows' coefficients and bounds (constant over a QP) are read from the workspace through the vector cache.
     const int K_planes = ad.n_planes;
     const bool rows_lds = (MODE == 0) && (uniform_i32(ad.rows_lds) != 0);
+    // (re-typed: through the Shm field these were flat accesses - a 64-bit address per value in vector registers)
+    double* const pco_lds = (MODE == 0) ? lds_ptr(sh.pco) : nullptr;
 #define PC_L(k, p) sh.pc[(p) * 3 + (k)]
 #define PC_G(k, p) sh.pcg[(p) * 3 + (k)]
 #define PROW(f, p) sh.prow[(p) * LD_prow + (f)]   // f: 0..3 y, 4..7 z, 8 timestep
-#define PCO(f, p) sh.pco[(size_t)(f) * sh.n_pco_ld + (p)]
+#define PCO(f, p) pco_lds[(f) * sh.n_pco_ld + (p)]
     auto plane_pass = [&](auto update_c, auto keep_c, auto lds_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
       constexpr bool KEEP = decltype(keep_c)::value;
@@ -1361,13 +1363,26 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             yy[q] = ROW(4 * p + q, R_Y);
           }
         });
-        if (ROWS_LDS && UPDATE && p < sh.n_pco) {   // the block's copy of the read-only coefficients (Shm::pco)
+        // The block's copy of the read-only coefficients (Shm::pco) covers the first n_pco planes.  Written as "LDS or workspace"
+        // per plane, the compiler merges the two sources into ONE flat load per value through a selected 64-bit address: sixteen
+        // addresses, hoisted out of the iteration loop, spilled, and reloaded from scratch in every iteration's plane pass.  So:
+        // an unconditional LDS read (index clamped into the copy), overridden from the workspace for the planes beyond it.
+        if constexpr (ROWS_LDS && UPDATE) {
+          const int pp = (p < sh.n_pco) ? p : 0;
           CSDO_FOR(q, 4, {
-            ca[q] = PCO(q, p);
-            cb[q] = PCO(4 + q, p);
-            cy[q] = PCO(8 + q, p);
-            uu[q] = PCO(12 + q, p);
+            ca[q] = PCO(q, pp);
+            cb[q] = PCO(4 + q, pp);
+            cy[q] = PCO(8 + q, pp);
+            uu[q] = PCO(12 + q, pp);
           });
+          if (p >= sh.n_pco) {
+            CSDO_FOR(q, 4, {
+              ca[q] = csdo_keep_f64(ROW(4 * p + q, R_CA));   // (kept apart from the LDS reads above: see the comment)
+              cb[q] = csdo_keep_f64(ROW(4 * p + q, R_CB));
+              cy[q] = csdo_keep_f64(ROW(4 * p + q, R_CY));
+              uu[q] = csdo_keep_f64(ROW(4 * p + q, R_U));
+            });
+          }
         } else {
           CSDO_FOR(q, 4, {
             ca[q] = ROW(4 * p + q, R_CA);

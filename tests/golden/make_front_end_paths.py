@@ -70,7 +70,7 @@ if __name__ == "__main__":
     listed["unsolved"] = sorted(set(listed["unsolved"]) | set(unsolved))
     with open(path, "w") as f:
         json.dump(listed, f, indent=1)
-    ok = [r for _, r in res if r is not None]
+    ok = [r for _, r in res if r is not None] or [(0.0, 0, 0)]
     print("solved %d of %d; search seconds mean %.2f max %.2f" % (len(ok), len(res), np.mean([r[0] for r in ok]),
                                                                    max(r[0] for r in ok)))
     print("unsolved:", unsolved)

@@ -46,7 +46,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
     rest = sh.lohi + 22 * st;
     if constexpr (MODE == 0) {
       sh.fx = aligned16(rest);
-      rest = sh.fx + 34 * st;
+      rest = sh.vec + LD_block * st;
     } else {
       sh.fx = nullptr;
     }

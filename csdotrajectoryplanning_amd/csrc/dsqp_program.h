@@ -227,7 +227,10 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 // the 512-thread kernel has per lane) the allocator spills a third of it to scratch, and a scratch reload inside a BCR
 // level costs more than the LDS read it replaced (measured: 160 ms against 140 ms per step on the map100 set); 60 doubles
 // leave the hot loop spill-free.  The other 33 sit in LDS (Shm::fx): read by one lane, once per sweep.
-constexpr int ER_REG = 24, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
+#if !defined(CSDO_ER_REG)
+#define CSDO_ER_REG 24   // measured again after the plane-pass fix (map100 set, ms per step): 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
+#endif
+constexpr int ER_REG = CSDO_ER_REG, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
 
 struct RowRegs {            // row lane of timestep t: the 16 home constraint rows and the 6 variables
   double c[NROW][3];        // scaled coefficients on own columns
@@ -278,7 +281,9 @@ enum WsSlot {
 // lane-major leading dimensions (doubles per lane) of the LDS arrays.  All are 2 * odd: 16-byte aligned lanes, and the
 // ds_read_b128 / ds_write_b128 of 16 consecutive lanes (also of lanes a power of two apart) fall into 16 different
 // 4-bank groups - conflict free.  (12 doubles, the former reduction stride, is 2-way conflicting.)
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 34,
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + 21 + 1) / 2) | 1),
+              // the block's per-timestep arrays (vec .. fx) double as the factorisation's exchange columns, 78 fields x stride
+              LD_block = (24 + LD_lohi + LD_fx) > 78 ? (24 + LD_lohi + LD_fx) : 78,
               LD_stash = 38, LD_tinv = 38, LD_prow = 10;
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]

@@ -639,7 +639,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // reciprocal square root per row and pass (and, in the workspace, a trip to HBM per access): 30 k cycles per pass.
     // Column maxima reach the timestep's lane through an LDS maximum (order independent), its column factors come back
     // through SU: same operations on the same operands as OSQP's scale_data, same results.
-    const bool rz_lds = (MODE == 0) && ((int64_t)21 * ad.n_planes <= (int64_t)LD_fx * sh.stride);
+    const bool rz_lds = (MODE == 0) && ((int64_t)21 * ad.n_planes <= (int64_t)(LD_block - 24 - LD_lohi) * sh.stride);
     auto rz = [&](const int r, const int f_lds, const int f_ws) __attribute__((always_inline)) -> double& {   // f_lds: a, b, c_yaw, E, u
       return rz_lds ? sh.fx[(size_t)f_lds * (size_t)rcap + (unsigned)r] : ROW(r, f_ws);
     };

@@ -54,7 +54,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     const int st = fac_stride(ad.Nt);
     // the same carve as dsqp_kernel_body.h (mode 0: bounds + the factor's LDS part in "LDS", rows' state too when
     // AgentDesc::rows_lds; 1: without the factor part; 3: lean)
-    std::vector<double> lds((size_t)80 * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N + TAIL_N * 38 +
+    std::vector<double> lds((size_t)LD_block * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N + TAIL_N * 38 +
                             (size_t)(3 + LD_prow) * hb.max_planes + 4 + 16 * 8, 0.0);
     std::vector<double> pc_ws((size_t)3 * hb.max_planes + 1, 0.0);
     Shm sh{};
@@ -73,7 +73,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
       rest = sh.lohi + 22 * st;
       if (mode == 0) {
         sh.fx = rest;
-        rest = sh.fx + 34 * st;
+        rest = sh.vec + LD_block * st;
       }
     } else {
       sh.carry2 = rest;

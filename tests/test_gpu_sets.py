@@ -85,7 +85,7 @@ def test_first_qp_in_the_regimes_the_baseline_sets_do_not_reach(gpu_handle, orac
     n_agents = {"room50": 600, "agents100": 1200}[workload]
     assert sum(w.Na for w in worlds) == n_agents
     if workload == "room50":
-        assert all(w.obstacles.shape[0] == 238 for w in worlds)
+        assert min(w.obstacles.shape[0] for w in worlds) >= 200, [w.obstacles.shape[0] for w in worlds]
     got = gpu_handle.solve_batch(worlds)
     ref = oracle.solve_batch(worlds, THREADS)
     d, dc, same = _per_agent(got, ref)

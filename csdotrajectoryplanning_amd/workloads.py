@@ -4,7 +4,7 @@ Instance files under tests/golden/instances/ are data files of the reference's b
 benchmark/map100by100, benchmark/room); BASELINE.json's configs name them.  Coarse paths (SURVEY 8d "Initial guesses"):
   front="auto"      the named workloads' default: the paths this repository's own front end (front_end.plan, PBS over hybrid
                     A*) produced for the instance, stored under tests/golden/front_end_paths/ by make_front_end_paths.py;
-                    the instances that search does not solve (unsolved.json: 2 of map100's 60, 11 of map50's 60) fall back
+                    the instances that search does not solve (unsolved.json: 1 of map100's 60, 3 of map50's 60, 1 of room50's 12, all 12 of agents100) fall back
                     to the stand-in so that every instance of a set takes part
   front="pbs"       run the search now; raises FrontEndFailed where it finds nothing
   front="stand-in"  synth.rollout_paths (GENERATOR_NAME): seeded primitive roll-outs, never fails, not collision-free;

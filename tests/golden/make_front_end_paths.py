@@ -34,13 +34,18 @@ def run(name):
     parm.keep_off_lower_goals = KEEP_OFF
     cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, parm)
     out = os.path.join(OUT, name.replace(".yaml", ".npz"))
+    fallback = False
+    if cp is None and KEEP_OFF:      # second attempt with the reference's rule set (csdo_front_end_parm::keep_off_lower_goals = 0)
+        parm.keep_off_lower_goals = 0
+        cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, veh, parm)
+        fallback = cp is not None
     if cp is None:
         if os.path.exists(out):
             os.remove(out)      # solved by an earlier version of the search
         return name, None
     np.savez_compressed(out, states=cp.states, actions=cp.actions,
                         path_off=cp.path_off, hl_expanded=cp.hl_expanded, ll_expanded=cp.ll_expanded)
-    return name, (cp.seconds, cp.hl_expanded, cp.ll_expanded)
+    return name, (cp.seconds, cp.hl_expanded, cp.ll_expanded, fallback)
 
 
 def _init(out, keep_off):
@@ -68,9 +73,11 @@ if __name__ == "__main__":
             listed = json.load(f)
         listed["unsolved"] = [n for n in listed["unsolved"] if pick not in n]
     listed["unsolved"] = sorted(set(listed["unsolved"]) | set(unsolved))
+    fb = set(n for n in listed.get("planned_with_reference_rules", []) if not (pick in n)) | set(n for n, r in res if r is not None and r[3])
+    listed["planned_with_reference_rules"] = sorted(fb)
     with open(path, "w") as f:
         json.dump(listed, f, indent=1)
-    ok = [r for _, r in res if r is not None] or [(0.0, 0, 0)]
+    ok = [r for _, r in res if r is not None] or [(0.0, 0, 0, False)]
     print("solved %d of %d; search seconds mean %.2f max %.2f" % (len(ok), len(res), np.mean([r[0] for r in ok]),
                                                                    max(r[0] for r in ok)))
     print("unsolved:", unsolved)

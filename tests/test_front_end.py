@@ -200,11 +200,23 @@ def test_stored_paths_are_what_the_search_returns():
         np.testing.assert_array_equal(cp.actions, ac)
         np.testing.assert_array_equal(cp.path_off, po)
     with open(os.path.join(workloads.PATHS_DIR, "unsolved.json")) as f:
-        unsolved = json.load(f)["unsolved"]
-    assert all(workloads.stored_paths(n) is None for n in unsolved)
+        listed = json.load(f)
+    assert all(workloads.stored_paths(n) is None for n in listed["unsolved"])
     solved100 = sum(workloads.stored_paths(workloads.MAP100_AGENTS50.format(k)) is not None for k in range(60))
     solved50 = sum(workloads.stored_paths(workloads.MAP50_AGENTS25_SET.format(k)) is not None for k in range(60))
-    assert (solved100, solved50) == (58, 49)
+    assert (solved100, solved50) == (59, 57)
+    # an instance the default rule set does not solve, stored from the second attempt with the reference's rule set
+    # (csdo_front_end_parm::keep_off_lower_goals = 0, profiles/r03_front_end_rules.json)
+    name = "map_50by50_obst25_agents25_ex1.yaml"
+    assert name in listed["planned_with_reference_rules"]
+    inst = _load(name)
+    parm = front_end.default_parm()
+    parm.keep_off_lower_goals = 0
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH, parm)
+    st, ac, po = workloads.stored_paths(name)
+    np.testing.assert_array_equal(cp.states, st)
+    np.testing.assert_array_equal(cp.actions, ac)
+    _check_paths(cp, inst)
 
 
 def test_limits_and_bad_arguments():

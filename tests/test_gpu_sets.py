@@ -85,7 +85,8 @@ def test_first_qp_in_the_regimes_the_baseline_sets_do_not_reach(gpu_handle, orac
     n_agents = {"room50": 600, "agents100": 1200}[workload]
     assert sum(w.Na for w in worlds) == n_agents
     if workload == "room50":
-        assert min(w.obstacles.shape[0] for w in worlds) >= 200, [w.obstacles.shape[0] for w in worlds]
+        n_obs = [w.obstacles.shape[0] for w in worlds]        # walls of 138 .. 238 discs (the BASELINE sets: 25 and 50)
+        assert min(n_obs) >= 130 and max(n_obs) == 238, n_obs
     got = gpu_handle.solve_batch(worlds)
     ref = oracle.solve_batch(worlds, THREADS)
     d, dc, same = _per_agent(got, ref)

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch brings its own HIP runtime, which must be the one libcsdo_hip.so binds to: a process that loads the library first and
+    # torch later ends up with two runtimes and torch finds no GPU (tests/test_gpu_dist.py uses torch.distributed on the device)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

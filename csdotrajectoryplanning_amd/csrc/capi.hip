@@ -626,6 +626,14 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
   if (!h || n_worlds < 1 || !states || !actions || !path_off || !Na || !goals || !veh || !parm || !outs) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   try {
+    const bool timing = std::getenv("CSDO_BRIDGE_TIMING") != nullptr;   // diagnostic: stage times to stderr
+    double t_mark = now_s();
+    auto lap = [&](const char* what) {
+      if (!timing) return;
+      const double t = now_s();
+      std::fprintf(stderr, "[bridge batch] %-28s %.3f ms\n", what, (t - t_mark) * 1e3);
+      t_mark = t;
+    };
     std::vector<BridgeCentres> C((size_t)n_worlds);
     std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
     for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));
@@ -652,6 +660,7 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
     pool([&](int w) { rcs[w] = bridge_interpolate(states[w], actions[w], path_off[w], Na[w], goals[w], veh, parm, &outs[w], C[w]); });
     for (int w = 0; w < n_worlds; ++w)
       if (rcs[w] != CSDO_OK) return fail(rcs[w]);
+    lap("interpolate (host pool)");
     // ---- layout: world w's eight centre arrays at cen_off[w] + k * NN[w]; its counts at cnt_off[w]; its offsets (NN + 1) at off_off[w]
     std::vector<size_t> NN((size_t)n_worlds), cen_off((size_t)n_worlds + 1, 0), off_off((size_t)n_worlds + 1, 0);
     for (int w = 0; w < n_worlds; ++w) {
@@ -671,6 +680,7 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
       const std::vector<float>* src[8] = {&C[w].xf, &C[w].yf, &C[w].xr, &C[w].yr, &C[w].xc, &C[w].yc, &C[w].cs, &C[w].sn};
       for (int k = 0; k < 8; ++k) std::memcpy(up + cen_off[w] + k * NN[w], src[k]->data(), NN[w] * sizeof(float));
     });
+    lap("stage centres");
     hipStream_t s = h->stream;
     HIP_OK(hipMemcpyAsync(h->k0_centres.p, up, cen_off[n_worlds] * sizeof(float), hipMemcpyHostToDevice, s), fail(CSDO_EDEVICE));
     HIP_OK(hipMemsetAsync(h->k0_flag.p, 0, (size_t)n_worlds * sizeof(int), s), fail(CSDO_EDEVICE));
@@ -692,6 +702,7 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
     }
     HIP_OK(hipMemcpyAsync(flags, h->k0_flag.p, (size_t)n_worlds * sizeof(int), hipMemcpyDeviceToHost, s), fail(CSDO_EDEVICE));
     HIP_OK(hipStreamSynchronize(s), fail(CSDO_EDEVICE));
+    lap("H2D + count + scan + sync");
     std::vector<size_t> pair_off((size_t)n_worlds + 1, 0);
     std::vector<int> collide((size_t)n_worlds);
     for (int w = 0; w < n_worlds; ++w) {
@@ -717,6 +728,7 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
       HIP_OK(hipMemcpyAsync((char*)h->bridge_down.p + o_coef, h->k0_coef.p, b_coef, hipMemcpyDeviceToHost, s), fail(CSDO_EDEVICE));
       HIP_OK(hipStreamSynchronize(s), fail(CSDO_EDEVICE));
     }
+    lap("emit + D2H + sync");
     const int32_t* pairs_all = (const int32_t*)h->bridge_down.p;
     const double* coef_all = (const double*)((const char*)h->bridge_down.p + o_coef);
     pool([&](int w) {
@@ -726,6 +738,7 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
     });
     for (int w = 0; w < n_worlds; ++w)
       if (rcs[w] != CSDO_OK) return fail(rcs[w]);
+    lap("planes (host pool)");
     return CSDO_OK;
   } catch (const std::bad_alloc&) {
     return CSDO_ENOMEM;

@@ -45,6 +45,10 @@ __device__ __forceinline__ int csdo_opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+__device__ __forceinline__ int csdo_opaque_s(int v) {   // the same for a block-uniform value (stays in a scalar register)
+  asm volatile("" : "+s"(v));
+  return v;
+}
 #define csdo_keep(v) csdo_opaque(v)   // a loaded value the compiler must not re-load (rematerialise) at its uses
 __device__ __forceinline__ double csdo_keep_f64(double v) {   // the same for a double: also keeps two loads from being merged
   asm volatile("" : "+v"(v));
@@ -101,6 +105,7 @@ __device__ __forceinline__ double csdo_keep_f64(double v) {   // the same for a 
 #elif defined(CSDO_LANE_MODE_SERIAL)
 #define csdo_keep(v) (v)
 #define csdo_keep_f64(v) (v)
+#define csdo_opaque_s(v) (v)
 #define CSDO_FN inline
 #define CSDO_NOINLINE inline
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)

@@ -11,19 +11,22 @@ namespace csdo {
 // (uniform base + field offset)[lane]: the field part stays scalar and the lane part is one unsigned 32-bit register, so
 // the access is `global_load v, v_lane, s[base]` - no per-field 64-bit address in vector registers (the compiler
 // otherwise hoists those out of the loops and spills them: a scratch reload in front of every workspace access)
-#define SX(k, t) (sh.facX + (size_t)(k) * (size_t)sh.stride)[(unsigned)(t)]
+#define SX(k, t) (sh.facX + (size_t)(k) * (size_t)csdo_opaque_s(sh.stride))[(unsigned)(t)]
 #define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
 // F_r of node t: the solver lane's registers for the first ER_REG entries, LDS for the rest and for the pivot inverse;
 // everything from the workspace for long horizons
 #define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t))))
 #define SINV(k, t) (MODE >= 1 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 // set-up stage scratch, field-major over the ADMM block's exchange arrays (see "assemble the QP")
-#define SU(k, t) sh.vec[(size_t)(k) * (size_t)sh.stride + (unsigned)(t)]
-#define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
-#define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)sh.stride)[(unsigned)(t)]
+#define SU(k, t) sh.vec[(size_t)(k) * (size_t)csdo_opaque_s(sh.stride) + (unsigned)(t)]
+// (the stride passes through an empty asm at every use: the per-slot base addresses - some sixty 64-bit scalars - are then formed
+// where they are used, two scalar instructions each, instead of being hoisted out of the SQP loop and held, or spilled, across
+// the ADMM iterations)
+#define CD(slot, t) (sh.cold + (size_t)(slot) * (size_t)csdo_opaque_s(sh.stride))[(unsigned)(t)]
+#define WS(slot, t) (sh.cold + (size_t)(slot) * (size_t)csdo_opaque_s(sh.stride))[(unsigned)(t)]
 // mode 0, between ADMM blocks: y (0..15), z (16..31), x (32..37) of the iterate a block has just finished, field-major in the
 // idle LDS arrays behind the six doubles per lane that the residual update's exchange (carry2) uses
-#define HX(f, t) (sh.lohi + (size_t)(6 + (f)) * (size_t)sh.stride)[(unsigned)(t)]
+#define HX(f, t) (sh.lohi + (size_t)(6 + (f)) * (size_t)csdo_opaque_s(sh.stride))[(unsigned)(t)]
 // the iterate as the residual update right behind a block reads it
 #define ITER_Y(i, t) ((MODE == 0) ? HX(i, t) : WS(W_Yv + (i), t))
 #define ITER_Z(i, t) ((MODE == 0) ? HX(NROW + (i), t) : WS(W_Zv + (i), t))
@@ -249,7 +252,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           // neighbour, 21..41 <- U_l of the right neighbour, 42..77 <- the new coupling from the right neighbour.  (Through
           // the workspace the absorption alone was 19 k cycles per level: the workspaces of the 32 agents of an XCD do not
           // fit its L2, so the exchange went to HBM and back.)
-#define XC(k, tt) sh.vec[(size_t)(k) * sh.stride + (unsigned)(tt)]
+#define XC(k, tt) sh.vec[(size_t)(k) * csdo_opaque_s(sh.stride) + (unsigned)(tt)]
 #define STASH(k) (*((MODE == 0) ? &XC(k, t) : &SH(stash, k, t)))
 #define PUT_UL(idx, v) (*((MODE == 0) ? &XC(21 + (idx), t - h) : &SX(idx, t)) = (v))
 #define PUT_CPL(idx, v) (*((MODE == 0) ? &XC(42 + (idx), t - h) : &SX(42 + (idx), t)) = (v))
@@ -1089,7 +1092,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     int qp_status = -10;  // OSQP_UNSOLVED
     double nrm[12];       // last update_info: see the residual block below
     CSDO_FOR(k, 12, { nrm[k] = 0.0; });
-    bool info_valid = false;
 
     // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective.  Like update_info it runs right
     // after a block: coefficients come from the row-lane registers, delta_y / bounds / scalings from the workspace in
@@ -1327,7 +1329,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_SUB(3);
       red_fold<12, false>(sh, Nt, nrm);
       CSDO_SUB(4);
-      info_valid = true;
     };
 
     // ---- the ADMM loop runs in blocks that end where osqp_solve would look at the iterate (termination check,
@@ -1650,11 +1651,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_SYNC();
 
+      // Every block ends where osqp_solve looks at the iterate (a termination check, a rho adaptation or the iteration cap), so
+      // the residuals are formed after EVERY block, in ONE place: the twelve norms are then defined right here in every trip of
+      // the loop and do not stay live across the iterations (24 scalar registers), and the large routine is inlined once.
+      update_info();
       can_check = chk && (iter % chk == 0);
-      info_valid = false;
       if (can_check) {
 #if !defined(CSDO_ABL_NOCHECK)
-        update_info();
 #if defined(CSDO_ABL_FIXED)
         check_termination(false);
         qp_status = -10;
@@ -1666,7 +1669,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       if (iter >= max_it) {
         finished = true;
       } else if (P.adaptive_rho_interval && (iter % P.adaptive_rho_interval == 0)) {
-        if (!info_valid) update_info();
         // compute_rho_estimate (auxil.c), scaled residuals
         double pri = nrm[3], dua = nrm[9];
         const double pri_n = osqp_max(nrm[4], nrm[5]);
@@ -1683,10 +1685,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
     }
     if (finished && qp_status == -10) {
-      if (!can_check) {
-        update_info();
-        check_termination(false);
-      }
+      if (!can_check) check_termination(false);
     }
     if (qp_status == -10) {
       if (!check_termination(true)) qp_status = -2;  // OSQP_MAX_ITER_REACHED

@@ -643,12 +643,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // Column maxima reach the timestep's lane through an LDS maximum (order independent), its column factors come back
     // through SU: same operations on the same operands as OSQP's scale_data, same results.
     const bool rz_lds = (MODE == 0) && ((int64_t)21 * ad.n_planes <= (int64_t)(LD_block - 24 - LD_lohi) * sh.stride);
-    auto rz = [&](const int r, const int f_lds, const int f_ws) __attribute__((always_inline)) -> double& {   // f_lds: a, b, c_yaw, E, u
-      return rz_lds ? sh.fx[(size_t)f_lds * (size_t)rcap + (unsigned)r] : ROW(r, f_ws);
-    };
-    auto rz_time = [&](const int pl_) __attribute__((always_inline)) -> int {
-      return rz_lds ? (int)sh.fx[(size_t)5 * (size_t)rcap + (unsigned)pl_] : (int)planes[pl_].t;
-    };
+    // (two instantiations of every loop over the rows, chosen per agent: one accessor that picks LDS or the workspace per access
+    // compiles to FLAT loads and stores through selected 64-bit addresses)
+    double* const fx_lds = (MODE == 0) ? lds_ptr(sh.fx) : nullptr;
+#define RZ(r, f_lds, f_ws) (*(L ? &fx_lds[(f_lds) * csdo_opaque_s((int)rcap) + (r)] : &ROW(r, f_ws)))   /* f_lds: a, b, c_yaw, E, u */
+#define RZ_TIME(pl_) (L ? (int)fx_lds[5 * csdo_opaque_s((int)rcap) + (pl_)] : (int)planes[pl_].t)
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       double dfx, dfy, drx, dry, exf, eyf, exr, eyr;
@@ -681,6 +680,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         SU(4, t) = fabs(S.Pvn);
       }
       CSDO_STHREADS(l, nthr) {   // inter-vehicle rows: (first pass: assemble,) column maxima to the timestep, row factor
+        auto body = [&](auto lds_c) __attribute__((always_inline)) {
+        constexpr bool L = decltype(lds_c)::value;
         for (int r = l; r < (int)rcap; r += nthr) {
           const int pl_ = r >> 2, q = r & 3;
           double a, bb, cy, e_acc;
@@ -697,15 +698,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             const double Dx = front ? SU(14, tp) : SU(16, tp), Dy = front ? SU(15, tp) : SU(17, tp);
             const double Ex = front ? SU(18, tp) : SU(20, tp), Ey = front ? SU(19, tp) : SU(21, tp);
             cy = a * Dx + bb * Dy;
-            rz(r, 4, R_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
+            RZ(r, 4, R_U) = -(cc + ((0.0 + a * Ex) + bb * Ey));
             e_acc = 1.0;
-            if (rz_lds && q == 0) sh.fx[(size_t)5 * (size_t)rcap + (unsigned)pl_] = (double)tp;
+            if (L && q == 0) fx_lds[5 * csdo_opaque_s((int)rcap) + pl_] = (double)tp;
           } else {
-            tp = rz_time(pl_);
-            a = rz(r, 0, R_CA);
-            bb = rz(r, 1, R_CB);
-            cy = rz(r, 2, R_CY);
-            e_acc = rz(r, 3, R_E);
+            tp = RZ_TIME(pl_);
+            a = RZ(r, 0, R_CA);
+            bb = RZ(r, 1, R_CB);
+            cy = RZ(r, 2, R_CY);
+            e_acc = RZ(r, 3, R_E);
           }
           const double fa = fabs(a), fb = fabs(bb), fc = fabs(cy);
           lds_max_nonneg(&SU(10, tp), fa);
@@ -713,11 +714,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           lds_max_nonneg(&SU(12, tp), fc);
           const double rn = nmax(nmax(fa, fb), fc);
           const double et = 1.0 / sqrt(limit_norm(rn));
-          rz(r, 0, R_CA) = a * et;
-          rz(r, 1, R_CB) = bb * et;
-          rz(r, 2, R_CY) = cy * et;
-          rz(r, 3, R_E) = e_acc * et;
+          RZ(r, 0, R_CA) = a * et;
+          RZ(r, 1, R_CB) = bb * et;
+          RZ(r, 2, R_CY) = cy * et;
+          RZ(r, 3, R_E) = e_acc * et;
         }
+        };
+        if (rz_lds) body(std::true_type{});
+        else body(std::false_type{});
       }
       CSDO_SYNC();
       CSDO_SUB(0);
@@ -785,12 +789,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         if (colsum > 5.0) sh.bcast[30 + (pass & 1)] = 1.0;
       }
       CSDO_STHREADS(l, nthr) {   // inter-vehicle rows only touch the columns of their own timestep
+        auto body = [&](auto lds_c) __attribute__((always_inline)) {
+        constexpr bool L = decltype(lds_c)::value;
         for (int r = l; r < (int)rcap; r += nthr) {
-          const int tp = rz_time(r >> 2);
-          rz(r, 0, R_CA) = rz(r, 0, R_CA) * SU(5, tp);
-          rz(r, 1, R_CB) = rz(r, 1, R_CB) * SU(6, tp);
-          rz(r, 2, R_CY) = rz(r, 2, R_CY) * SU(7, tp);
+          const int tp = RZ_TIME(r >> 2);
+          RZ(r, 0, R_CA) = RZ(r, 0, R_CA) * SU(5, tp);
+          RZ(r, 1, R_CB) = RZ(r, 1, R_CB) * SU(6, tp);
+          RZ(r, 2, R_CY) = RZ(r, 2, R_CY) * SU(7, tp);
         }
+        };
+        if (rz_lds) body(std::true_type{});
+        else body(std::false_type{});
       }
       CSDO_SYNC();
       CSDO_SUB(2);
@@ -848,21 +857,26 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     }
     CSDO_SYNC();
     CSDO_STHREADS(l, nthr) {   // inter-vehicle rows: z <- A x, y <- 0; the master copy goes to the workspace
+      auto body = [&](auto lds_c) __attribute__((always_inline)) {
+      constexpr bool L = decltype(lds_c)::value;
       for (int r = l; r < (int)rcap; r += nthr) {
-        const int tp = rz_time(r >> 2);
-        const double a = rz(r, 0, R_CA), bb = rz(r, 1, R_CB), cy = rz(r, 2, R_CY), e_acc = rz(r, 3, R_E);
+        const int tp = RZ_TIME(r >> 2);
+        const double a = RZ(r, 0, R_CA), bb = RZ(r, 1, R_CB), cy = RZ(r, 2, R_CY), e_acc = RZ(r, 3, R_E);
         ROW(r, R_Z) = (a * SU(5, tp) + bb * SU(6, tp)) + cy * SU(7, tp);
         ROW(r, R_Y) = 0.0;
         ROW(r, R_DY) = 0.0;
-        const double u_scaled = e_acc * rz(r, 4, R_U);
+        const double u_scaled = e_acc * RZ(r, 4, R_U);
         ROW(r, R_U) = u_scaled;
-        if (rz_lds) {   // publish what the set-up stages kept in LDS
+        if (L) {   // publish what the set-up stages kept in LDS
           ROW(r, R_CA) = a;
           ROW(r, R_CB) = bb;
           ROW(r, R_CY) = cy;
           ROW(r, R_E) = e_acc;
         }
       }
+      };
+      if (rz_lds) body(std::true_type{});
+      else body(std::false_type{});
     }
     CSDO_LANES(t) {  // z <- A x, y <- 0
       LaneState& S = CSDO_LS(t);
@@ -1841,6 +1855,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #undef PROW
 }
 
+#undef RZ
+#undef RZ_TIME
 #undef SH
 #undef SU
 #undef SX

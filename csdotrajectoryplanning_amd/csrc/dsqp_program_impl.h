@@ -757,6 +757,18 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_norm(cn_[j])) : 1.0; });
         CSDO_FOR(k, 5, { SU(5 + k, t) = Dt[k]; });
         if (t == 0) sh.bcast[30 + ((pass + 1) & 1)] = 0.0;   // the other pass parity's cost-scaling flag
+        // everything that only needs the lane's own factors is scaled right here; what needs the right neighbour's column
+        // factors (the kinematic rows' coefficients on t+1, P's off-diagonal) waits for the barrier, so that only four row
+        // factors and the lane's six column factors stay live across it
+        CSDO_FOR(i, NROW, {
+          CSDO_FOR(s, 3, {
+            if constexpr (row_col(i, s) >= 0) S.c[i][s] = (S.c[i][s] * Et[i]) * Dt[row_col(i, s)];
+          });
+          SU(14 + i, t) = (pass == 0) ? Et[i] : SU(14 + i, t) * Et[i];
+        });
+        S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
+        S.Pww = (S.Pww * Dt[5]) * Dt[5];
+        CSDO_FOR(j, 6, { S.dsc[j] = S.dsc[j] * Dt[j]; });
       }
       CSDO_SYNC();
       CSDO_SUB(1);
@@ -766,20 +778,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double* Et = S.z;
         double Dn[5] = {1, 1, 1, 1, 1};
         if (t < Nm) CSDO_FOR(k, 5, { Dn[k] = SU(5 + k, t + 1); });
-        CSDO_FOR(i, NROW, {
-          CSDO_FOR(s, 3, {
-            if constexpr (row_col(i, s) >= 0) S.c[i][s] = (S.c[i][s] * Et[i]) * Dt[row_col(i, s)];
-          });
-          if constexpr (i < 4) S.cn[i] = (S.cn[i] * Et[i]) * Dn[i];
-          SU(14 + i, t) = (pass == 0) ? Et[i] : SU(14 + i, t) * Et[i];
-        });
+        CSDO_FOR(i, 4, { S.cn[i] = (S.cn[i] * Et[i]) * Dn[i]; });
         // scaled |P(v_{t-1}, v_t)| as its owner computes it
         double pvn_left = 0.0;
         if (t > 0) pvn_left = (SU(4, t - 1) * SU(9, t - 1)) * Dt[4];
-        S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
-        S.Pww = (S.Pww * Dt[5]) * Dt[5];
         S.Pvn = (S.Pvn * Dt[4]) * Dn[4];
-        CSDO_FOR(j, 6, { S.dsc[j] = S.dsc[j] * Dt[j]; });
         // cost normalisation: mean column norm of the scaled P
         double colsum = 0.0;
         if (t < Nm) colsum = nmax(nmax(fabs(S.Pvv), fabs(S.Pvn)), pvn_left) + fabs(S.Pww);

@@ -899,11 +899,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         });
         WS(W_LO + i, t) = S.lo[i];
         WS(W_HI + i, t) = S.hi[i];
-        WS(W_Yv + i, t) = S.y[i];
-        WS(W_Zv + i, t) = S.z[i];
       });
       CSDO_FOR(i, 4, { WS(W_CN + i, t) = S.cn[i]; });
-      CSDO_FOR(j, 6, { WS(W_X + j, t) = S.x[j]; });
       WS(W_P + 0, t) = S.Pvv;
       WS(W_P + 1, t) = S.Pww;
       WS(W_P + 2, t) = S.Pvn;
@@ -1110,6 +1107,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     double nrm[12];       // last update_info: see the residual block below
     CSDO_FOR(k, 12, { nrm[k] = 0.0; });
 
+    const int K_planes = ad.n_planes;
+    const bool rows_lds = (MODE == 0) && (uniform_i32(ad.rows_lds) != 0);
+    // (re-typed: through the Shm field these were flat accesses - a 64-bit address per value in vector registers)
+    double* const pco_lds = (MODE == 0) ? lds_ptr(sh.pco) : nullptr;
+#define PC_L(k, p) sh.pc[(p) * 3 + (k)]
+#define PC_G(k, p) sh.pcg[(p) * 3 + (k)]
+#define PROW(f, p) sh.prow[(p) * LD_prow + (f)]   // f: 0..3 y, 4..7 z, 8 timestep
+#define PCO(f, p) pco_lds[(f) * sh.n_pco_ld + (p)]
     // primal infeasibility certificate test (auxil.c is_primal_infeasible); collective.  Like update_info it runs right
     // after a block: coefficients come from the row-lane registers, delta_y / bounds / scalings from the workspace in
     // one batch of loads.
@@ -1233,33 +1238,30 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     };
 
     // update_info (auxil.c): residuals of the current (x, z, y), unscaled for the termination test and scaled for
-    // adapt_rho.  Always called right after an ADMM block has written its iterate back to the workspace; everything is
-    // read from there.
+    // adapt_rho.  Runs once after every block, while the row lanes still hold the block's state (coefficients, x, y, z) in
+    // registers; only the scalings come from the workspace.  The inter-vehicle rows' duals and slacks are read where the block
+    // kept them (LDS for rows_lds agents), their coefficients from the block's LDS copy where it has one.
     auto update_info = [&]() __attribute__((always_inline)) {
       CSDO_MARK("info_begin");
       CSDO_PHASE(10);
-      CSDO_LANES(t) {
-        const unsigned act_ = (unsigned)WS(W_ACT, t);
-        CSDO_FOR(k, 5, { SH(carry2, k, t) = ITER_X(k, t); });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
-        CSDO_FOR(k, 4, {                                          // to t+1: A'y share of the kinematic rows
-          SH(carry, k, t) = (act_ & (1u << k)) ? WS(W_CN + k, t) * ITER_Y(k, t) : 0.0;
-        });
-        SH(carry, 4, t) = ITER_X(4, t);
+      CSDO_LANES_HOT(t) {
+        LaneState& S = CSDO_LS(t);
+        CSDO_FOR(k, 5, { SH(carry2, k, t) = S.x[k]; });   // to t-1: x_{t+1} cols 0..3 and v_{t+1}
+        // to t+1: A'y share of the kinematic rows (rows that do not exist have cn = y = 0)
+        CSDO_FOR(k, 4, { SH(carry, k, t) = S.cn[k] * S.y[k]; });
+        SH(carry, 4, t) = S.x[4];
         SH(carry, 5, t) = WS(W_P + 2, t);
       }
       CSDO_SYNC();
       CSDO_SUB_RESET();
-      CSDO_LANES(t) {
-        // the iterate and the coefficients come from the workspace (the block has just written x, y, z back), into
-        // temporaries of this phase: the row lanes' hot register cache is dead here
-        const unsigned act_ = (unsigned)WS(W_ACT, t);
+      CSDO_LANES_HOT(t) {
+        LaneState& S = CSDO_LS(t);
         const int ncols_ = (t < Nm) ? 6 : 4;
-        double x_[6];
-        CSDO_FOR(j, 6, { x_[j] = ITER_X(j, t); });
         double einv[NROW], dinv[6];
         CSDO_FOR(i, NROW, { einv[i] = WS(C_E + i, t); });
         CSDO_FOR(j, 6, { dinv[j] = WS(C_D + j, t); });
         const double pvv = WS(W_P + 0, t), pww = WS(W_P + 1, t), pvn = WS(W_P + 2, t);
+        const int k0 = tstart[t], k1 = tstart[t + 1];
         double xn[4] = {0, 0, 0, 0};
         double vn = 0.0, vp = 0.0, pvn_left = 0.0;
         if (t < Nm) {
@@ -1273,52 +1275,67 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           pvn_left = SH(carry, 5, t - 1);
         }
         double p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        (void)act_;
         CSDO_FOR(i, NROW, {   // (every row: the ones that do not exist at this t are all-zero with E = 1 and change no maximum)
           {
-            double ci[3] = {0, 0, 0};
-            CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) ci[s] = WS(W_C + 3 * i + s, t);
-            });
             double ax = 0.0;
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) ax = fma(ci[s], x_[row_col(i, s)], ax);
+              if constexpr (row_col(i, s) >= 0) ax = fma(S.c[i][s], S.x[row_col(i, s)], ax);
             });
-            if constexpr (i < 4) ax = fma(WS(W_CN + i, t), xn[i], ax);
-            const double zi = ITER_Z(i, t), yi = ITER_Y(i, t);
+            if constexpr (i < 4) ax = fma(S.cn[i], xn[i], ax);
+            const double zi = S.z[i], yi = S.y[i];
             const double ei = 1.0 / einv[i];
             const double res = ax - zi;
-            p[0] = dmax(p[0], fabs(ei * res));
-            p[1] = dmax(p[1], fabs(ei * zi));
-            p[2] = dmax(p[2], fabs(ei * ax));
-            p[3] = dmax(p[3], fabs(res));
-            p[4] = dmax(p[4], fabs(zi));
-            p[5] = dmax(p[5], fabs(ax));
+            p[0] = nmax(p[0], fabs(ei * res));
+            p[1] = nmax(p[1], fabs(ei * zi));
+            p[2] = nmax(p[2], fabs(ei * ax));
+            p[3] = nmax(p[3], fabs(res));
+            p[4] = nmax(p[4], fabs(zi));
+            p[5] = nmax(p[5], fabs(ax));
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(ci[s], yi, Aty[row_col(i, s)]);
+              if constexpr (row_col(i, s) >= 0) Aty[row_col(i, s)] = fma(S.c[i][s], yi, Aty[row_col(i, s)]);
             });
           }
         });
-        for (int k = tstart[t]; k < tstart[t + 1]; ++k) {
+        for (int k = k0; k < k1; ++k) {
           double ca[4], cb[4], cy[4], zz[4], yy[4], ee[4];
+          CSDO_FOR(q, 4, { ee[q] = ROW(4 * k + q, R_E); });
+          if (rows_lds) {
+            CSDO_FOR(q, 4, {
+              yy[q] = PROW(q, k);
+              zz[q] = PROW(4 + q, k);
+            });
+            const int kk = (k < sh.n_pco) ? k : 0;
+            CSDO_FOR(q, 4, {
+              ca[q] = PCO(q, kk);
+              cb[q] = PCO(4 + q, kk);
+              cy[q] = PCO(8 + q, kk);
+            });
+            if (k >= sh.n_pco) {
+              CSDO_FOR(q, 4, {
+                ca[q] = csdo_keep_f64(ROW(4 * k + q, R_CA));
+                cb[q] = csdo_keep_f64(ROW(4 * k + q, R_CB));
+                cy[q] = csdo_keep_f64(ROW(4 * k + q, R_CY));
+              });
+            }
+          } else {
+            CSDO_FOR(q, 4, {
+              zz[q] = ROW(4 * k + q, R_Z);
+              yy[q] = ROW(4 * k + q, R_Y);
+              ca[q] = ROW(4 * k + q, R_CA);
+              cb[q] = ROW(4 * k + q, R_CB);
+              cy[q] = ROW(4 * k + q, R_CY);
+            });
+          }
           CSDO_FOR(q, 4, {
-            ca[q] = ROW(4 * k + q, R_CA);
-            cb[q] = ROW(4 * k + q, R_CB);
-            cy[q] = ROW(4 * k + q, R_CY);
-            zz[q] = ROW(4 * k + q, R_Z);
-            yy[q] = ROW(4 * k + q, R_Y);
-            ee[q] = ROW(4 * k + q, R_E);
-          });
-          CSDO_FOR(q, 4, {
-            const double ax = (ca[q] * x_[0] + cb[q] * x_[1]) + cy[q] * x_[2];
+            const double ax = (ca[q] * S.x[0] + cb[q] * S.x[1]) + cy[q] * S.x[2];
             const double ei = 1.0 / ee[q];
             const double res = ax - zz[q];
-            p[0] = dmax(p[0], fabs(ei * res));
-            p[1] = dmax(p[1], fabs(ei * zz[q]));
-            p[2] = dmax(p[2], fabs(ei * ax));
-            p[3] = dmax(p[3], fabs(res));
-            p[4] = dmax(p[4], fabs(zz[q]));
-            p[5] = dmax(p[5], fabs(ax));
+            p[0] = nmax(p[0], fabs(ei * res));
+            p[1] = nmax(p[1], fabs(ei * zz[q]));
+            p[2] = nmax(p[2], fabs(ei * ax));
+            p[3] = nmax(p[3], fabs(res));
+            p[4] = nmax(p[4], fabs(zz[q]));
+            p[5] = nmax(p[5], fabs(ax));
             Aty[0] = fma(ca[q], yy[q], Aty[0]);
             Aty[1] = fma(cb[q], yy[q], Aty[1]);
             Aty[2] = fma(cy[q], yy[q], Aty[2]);
@@ -1326,19 +1343,19 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         double Px[6] = {0, 0, 0, 0, 0, 0};
         if (t < Nm) {
-          Px[4] = (pvv * x_[4] + pvn * vn) + pvn_left * vp;
-          Px[5] = pww * x_[5];
+          Px[4] = (pvv * S.x[4] + pvn * vn) + pvn_left * vp;
+          Px[5] = pww * S.x[5];
         }
         CSDO_FOR(j, 6, {
           if (j < ncols_) {
             const double dj = 1.0 / dinv[j];
             const double dr = (0.0 + Px[j]) + Aty[j];
-            p[6] = dmax(p[6], fabs(dj * dr));
-            p[7] = dmax(p[7], fabs(dj * Aty[j]));
-            p[8] = dmax(p[8], fabs(dj * Px[j]));
-            p[9] = dmax(p[9], fabs(dr));
-            p[10] = dmax(p[10], fabs(Aty[j]));
-            p[11] = dmax(p[11], fabs(Px[j]));
+            p[6] = nmax(p[6], fabs(dj * dr));
+            p[7] = nmax(p[7], fabs(dj * Aty[j]));
+            p[8] = nmax(p[8], fabs(dj * Px[j]));
+            p[9] = nmax(p[9], fabs(dr));
+            p[10] = nmax(p[10], fabs(Aty[j]));
+            p[11] = nmax(p[11], fabs(Px[j]));
           }
         });
         red_put<12>(sh, t, p);
@@ -1357,14 +1374,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // plane's share of A'(rho z - y) in pc[p][0..2]; the solver lane of that timestep adds its planes' shares to its rhs.
     // ROWS_LDS: duals, slacks, the plane's timestep and the shares live in LDS for the block (Shm::prow, Shm::pc); the
     // rows' coefficients and bounds (constant over a QP) are read from the workspace through the vector cache.
-    const int K_planes = ad.n_planes;
-    const bool rows_lds = (MODE == 0) && (uniform_i32(ad.rows_lds) != 0);
-    // (re-typed: through the Shm field these were flat accesses - a 64-bit address per value in vector registers)
-    double* const pco_lds = (MODE == 0) ? lds_ptr(sh.pco) : nullptr;
-#define PC_L(k, p) sh.pc[(p) * 3 + (k)]
-#define PC_G(k, p) sh.pcg[(p) * 3 + (k)]
-#define PROW(f, p) sh.prow[(p) * LD_prow + (f)]   // f: 0..3 y, 4..7 z, 8 timestep
-#define PCO(f, p) pco_lds[(f) * sh.n_pco_ld + (p)]
     auto plane_pass = [&](auto update_c, auto keep_c, auto lds_c, const int lane, const int nthr, const double rho_now) __attribute__((always_inline)) {
       constexpr bool UPDATE = decltype(update_c)::value;
       constexpr bool KEEP = decltype(keep_c)::value;
@@ -1446,6 +1455,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 
     bool can_check = false;
     bool finished = false;
+    bool first_block = true;
     iter = 0;
     while (!finished) {
       if (need_factor) {
@@ -1476,33 +1486,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
       };
       CSDO_SUB_RESET();
-      CSDO_LANES(t) {  // load the row-lane cache, in stages: with every load of it in flight at once (some 90 doubles) this
-        // is the row role's register peak, and what the allocator spills for it stays spilled in the iterations
+      CSDO_LANES_HOT(t) {
+        // The row lane's state - coefficients, duals, slacks, iterate, row classes - stays in its registers from the warm start
+        // to the end of the QP (the row waves only wait at barriers during a factorisation, and the residual update reads the
+        // registers): no write-back after a block, no reload in front of the next (it was some 90 dependent workspace loads per
+        // lane and block).  Only the bounds, read once per iteration, are staged into LDS again: the factorisation's exchange
+        // columns and the residual update's hand-over overwrite them (layout: Shm::lohi).
         LaneState& S = CSDO_LS(t);
-        // bounds are read once per iteration: LDS, not registers (layout: Shm::lohi)
         if constexpr (MODE != 3) {
           CSDO_FOR(i, 13, { SH(lohi, i, t) = WS(W_LO + i, t); });
-          CSDO_STAGE();
           CSDO_FOR(i, 9, { SH(lohi, 13 + i, t) = WS(W_HI + 7 + i, t); });
-          CSDO_STAGE();
         }
-        CSDO_FOR(i, NROW, {
-          S.y[i] = WS(W_Yv + i, t);
-          S.z[i] = WS(W_Zv + i, t);
-        });
-        CSDO_STAGE();
-        CSDO_FOR(i, NROW, {
-          CSDO_FOR(s_, 3, {
-            if constexpr (row_col(i, s_) >= 0) S.c[i][s_] = WS(W_C + 3 * i + s_, t);
-          });
-        });
-        CSDO_FOR(i, 4, { S.cn[i] = WS(W_CN + i, t); });
-        CSDO_FOR(j, 6, { S.x[j] = WS(W_X + j, t); });
-        S.act = (unsigned)WS(W_ACT, t);
-        S.eqmask = (unsigned)WS(W_EQ, t);
-        S.loosemask = (unsigned)WS(W_LOOSE, t);
-        S.ncols = (t < Nm) ? 6 : 4;
-        CSDO_STAGE();
         publish_rhs(S, t);
       }
       CSDO_SLANES(t) {  // load the solver-lane cache: 60 doubles of the node's factor in registers, 33 in LDS
@@ -1518,16 +1512,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
         V.ts1 = csdo_keep(tstart[t + 1]);
       }
-      if (rows_lds) {   // the inter-vehicle rows' duals, slacks and timesteps move into LDS for the block
-        CSDO_STHREADS(l, nthr) {
-          for (int p = l; p < K_planes; p += nthr) {
+      if (rows_lds) {   // the inter-vehicle rows' duals, slacks and timesteps live in LDS for the whole QP (nothing else uses
+        CSDO_STHREADS(l, nthr) {   // that part of it): staged in front of the QP's first block only
+          for (int p = l; p < (first_block ? K_planes : 0); p += nthr) {
             CSDO_FOR(q, 4, {
               PROW(q, p) = ROW(4 * p + q, R_Y);
               PROW(4 + q, p) = ROW(4 * p + q, R_Z);
             });
             PROW(8, p) = (double)planes[p].t;
           }
-          for (int p = l; p < sh.n_pco; p += nthr) {
+          for (int p = l; p < (first_block ? sh.n_pco : 0); p += nthr) {
             CSDO_FOR(q, 4, {
               PCO(q, p) = ROW(4 * p + q, R_CA);
               PCO(4 + q, p) = ROW(4 * p + q, R_CB);
@@ -1632,46 +1626,20 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         CSDO_SYNC();
       };
+      first_block = false;
       while (iter < stop - 1) {
         ++iter;
         iteration(std::false_type{});
       }
       ++iter;
       iteration(std::true_type{});
+      update_info();
       CSDO_PHASE(12);
-      CSDO_LANES(t) {  // write the iterate back: nothing else changes inside a block
-        LaneState& S = CSDO_LS(t);
-        if constexpr (MODE == 0) {
-          // ... and hand it to the residual update through LDS as well (the block's arrays are dead now): a workspace load
-          // queued behind these workspace stores waits until they are acknowledged
-          CSDO_FOR(i, NROW, {
-            HX(i, t) = S.y[i];
-            HX(NROW + i, t) = S.z[i];
-          });
-          CSDO_FOR(j, 6, { HX(2 * NROW + j, t) = S.x[j]; });
-        }
-        CSDO_FOR(i, NROW, {
-          WS(W_Yv + i, t) = S.y[i];
-          WS(W_Zv + i, t) = S.z[i];
-        });
-        CSDO_FOR(j, 6, { WS(W_X + j, t) = S.x[j]; });
-      }
-      if (rows_lds) {   // ... and the inter-vehicle rows' duals and slacks go back to the workspace for the cold phases
-        CSDO_STHREADS(l, nthr) {
-          for (int p = l; p < K_planes; p += nthr) {
-            CSDO_FOR(q, 4, {
-              ROW(4 * p + q, R_Y) = PROW(q, p);
-              ROW(4 * p + q, R_Z) = PROW(4 + q, p);
-            });
-          }
-        }
-      }
       CSDO_SYNC();
 
       // Every block ends where osqp_solve looks at the iterate (a termination check, a rho adaptation or the iteration cap), so
       // the residuals are formed after EVERY block, in ONE place: the twelve norms are then defined right here in every trip of
       // the loop and do not stay live across the iterations (24 scalar registers), and the large routine is inlined once.
-      update_info();
       can_check = chk && (iter % chk == 0);
       if (can_check) {
 #if !defined(CSDO_ABL_NOCHECK)
@@ -1720,7 +1688,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_FOR(j, 6, {
         if (j < S.ncols) {
           const double s0 = CD(C_SOL0 + j, t);
-          const double sn = keep_prev ? s0 : CD(C_D + j, t) * WS(W_X + j, t);
+          const double sn = keep_prev ? s0 : CD(C_D + j, t) * S.x[j];
           CD(C_SOL + j, t) = sn;
           const double d = sn - s0;
           acc = fma(d, d, acc);

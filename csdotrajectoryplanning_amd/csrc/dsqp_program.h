@@ -359,12 +359,42 @@ CSDO_FN double wave_shfl_down(double v, int off) {
 }
 #endif
 
+#if defined(CSDO_LANE_MODE_DEVICE)
+CSDO_FN double wave_shfl_xor(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, 64);
+  hi = __shfl_xor(hi, mask, 64);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
 // out[k] = reduction over lanes 0..Nt-1 of slot k.  IS_SUM=false: max with NaNs ignored.  Collective.
+// Maxima (order independent) take the wide path: the first wave's lane (k, segment) scans every fourth lane's slot k and
+// two butterfly steps join the four segments - the slot-after-slot fold with a six-step shuffle tree per slot was 15 k cycles
+// for the twelve norms of update_info.  Sums keep the fixed order that the serial build reproduces.
 template <int K, bool IS_SUM>
 CSDO_FN void red_fold(const Shm& sh, int Nt, double (&out)[K]) {
   CSDO_SYNC();
 #if defined(CSDO_LANE_MODE_DEVICE)
   const int tid = (int)threadIdx.x;
+  if constexpr (!IS_SUM && K > 2) {
+    static_assert(K <= 16, "one 16-lane row per segment");
+    if (tid < 64) {
+      const int k = tid & 15, seg = tid >> 4;
+      double acc = 0.0;
+      if (k < K) {
+#pragma unroll 8
+        for (int j = seg; j < Nt; j += 4) acc = dmax(acc, sh.red[j * LD_red + k]);
+      }
+      acc = dmax(acc, wave_shfl_xor(acc, 16));
+      acc = dmax(acc, wave_shfl_xor(acc, 32));
+      if (tid < K) sh.bcast[tid] = acc;
+    }
+    __syncthreads();
+    CSDO_FOR(k, K, { out[k] = uniform_f64(sh.bcast[k]); });
+    __syncthreads();
+    return;
+  }
   if (tid < 64) {
     CSDO_FOR(k, K, {
       double acc = 0.0;

@@ -1,10 +1,10 @@
 #!/bin/bash
-# chain parity reports (scripts/chain_parity.py) for both benchmark sets + a short bench line.  usage: gpu_chain.sh <tag>
+# chain parity reports + outlier fixtures (scripts/chain_parity.py) for both benchmark sets.  usage: gpu_chain.sh <tag>
+# afterwards: cp gpurun_out/<tag>/chain_outliers_*.json tests/golden/ ; cp gpurun_out/<tag>/chain_*.json profiles/ (renamed per round)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 TAG=${1:-chain}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 900 python scripts/chain_parity.py --workload map100 --out $O/chain_map100.json > $O/chain_map100.log 2>&1; echo "chain map100 rc=$?"; tail -3 $O/chain_map100.log
-timeout 900 python scripts/chain_parity.py --workload map50 --out $O/chain_map50.json > $O/chain_map50.log 2>&1; echo "chain map50 rc=$?"; tail -3 $O/chain_map50.log
-timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_map100.json 2> $O/bench_map100.err; echo "bench rc=$?"
-tail -c 600 $O/bench_map100.json
+for w in map100 map50; do
+  timeout 1200 python scripts/chain_parity.py --workload $w --out $O/chain_$w.json --fixture $O/chain_outliers_$w.json > $O/chain_$w.log 2>&1; echo "chain $w rc=$?"; tail -2 $O/chain_$w.log
+done

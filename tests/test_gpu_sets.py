@@ -138,7 +138,8 @@ def test_second_qp_with_flips_listed(gpu_handle, oracle, workload):
 # check or a 0.1 m box growth step flips - and the ORACLE differs from ITSELF built with fused multiply-adds by the same
 # factors on the same agents (growth 3.3-9.2 per cut against 3.3-8.7 for HIP vs oracle, the same worst single steps).  So:
 #   * the bars below are fitted to the measured front-end workloads (map100: 2999/3000 identical counts, 2972 within 1e-4,
-#     max 0.49; map50: 1500/1500, 1497, max 4.5e-3);
+#     max 0.49; map50: 1500/1500 identical counts and 1500/1500 within 1e-4 - north_star's bar met on every agent - since the
+#     instances the default search rules do not solve are planned with the reference's rules instead of the stand-in);
 #   * every agent beyond 1e-4 must be LISTED in tests/golden/chain_outliers_<workload>.json (written by scripts/chain_parity.py
 #     on the GPU) or be an agent on which the oracle differs from its own FMA build by more than 1e-6 in this very run: a new
 #     outlier on an agent the reference algorithm is NOT sensitive on fails;
@@ -146,7 +147,7 @@ def test_second_qp_with_flips_listed(gpu_handle, oracle, workload):
 #     the FMA oracle and asserts the growth law.
 CHAIN_BARS = {   # min fraction with identical counts, min fraction <= 1e-6, min fraction <= 1e-4, max median, max
     "map100": dict(same=0.999, le_1e6=0.93, le_1e4=0.985, median=1e-7, max=1.0),
-    "map50": dict(same=0.999, le_1e6=0.98, le_1e4=0.997, median=1e-8, max=1.0),
+    "map50": dict(same=1.0, le_1e6=0.98, le_1e4=1.0, median=1e-8, max=1.0e-4),
 }
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -243,7 +244,8 @@ def test_outlier_growth_is_the_reference_algorithms_own_amplification(gpu_handle
     fx = _fixture(workload)
     worlds = _set(workload)
     singles = [worlds[o["world"]].subset(o["agent"], o["agent"] + 1) for o in fx["outliers"]]
-    assert singles, "no outliers listed"
+    if not singles:
+        pytest.skip("no agent of the %s set is beyond 1e-4 of the oracle (tests/golden/chain_outliers_%s.json)" % (workload, workload))
     D = {name: np.zeros((len(singles), 10)) for name in ("hip_oracle", "fma_oracle", "hip_emu")}
     for k in range(1, 11):
         ws = [_with_max_iter(w, k) for w in singles]

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Full GPU session: every -m gpu test, the three workloads' bench lines, parity reports, rocprofv3 profiles.  usage: gpu_full.sh <tag>
+# Full GPU session: every -m gpu test, the bench lines of all workloads, rocprofv3 profiles.  usage: gpu_full.sh <tag>
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/$TAG; mkdir -p $O
 python - <<'PY' > $O/host_info.txt 2>&1
 import os
@@ -12,11 +12,14 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys
     except Exception as e: print(f, "n/a")
 PY
 cat $O/host_info.txt
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -rA > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
-timeout 600 python scripts/first_qp_parity.py --backend gpu --workload map100 --out $O/parity_map100.json > /dev/null 2> $O/parity_map100.err
-timeout 600 python scripts/first_qp_parity.py --backend gpu --workload map50 --out $O/parity_map50.json > /dev/null 2> $O/parity_map50.err
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -rA > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 timeout 600 python bench.py > $O/bench_map100.json 2> $O/bench_map100.err; echo "bench map100 rc=$?"
-timeout 600 python bench.py --workload map50 > $O/bench_map50.json 2> $O/bench_map50.err; echo "bench map50 rc=$?"
-timeout 600 python bench.py --workload synth1024 > $O/bench_synth1024.json 2> $O/bench_synth1024.err; echo "bench synth rc=$?"
+for w in map50 synth1024 room50 agents100; do
+  timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w rc=$?"
+done
+timeout 600 python bench.py --force-dist --no-cpu-baseline > $O/bench_map100_force_dist.json 2> $O/bench_map100_force_dist.err; echo "bench force-dist rc=$?"
 bash scripts/profile_round.sh $TAG map100 > $O/profile_map100.log 2>&1; tail -3 $O/profile_map100.log
 bash scripts/profile_round.sh $TAG map50 > $O/profile_map50.log 2>&1; tail -3 $O/profile_map50.log
+bash scripts/profile_round.sh $TAG synth1024 > $O/profile_synth1024.log 2>&1; tail -3 $O/profile_synth1024.log
+timeout 600 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 map100 > $O/phases_map100.txt 2>&1
+timeout 600 python scripts/profile_phases_sum.py 0,2,3,4,5,6,7,9 map50 > $O/phases_map50.txt 2>&1

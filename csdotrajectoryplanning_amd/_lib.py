@@ -58,6 +58,7 @@ def lib():
         L.csdo_preprocess_device_batch.argtypes = [H, C.c_int32, PP(abi.c_double_p), PP(abi.c_int32_p), PP(abi.c_int32_p),
                                                    abi.c_int32_p, PP(abi.c_double_p), PP(abi.Vehicle), PP(abi.QpParm),
                                                    PP(abi.BridgeOut)]
+        L.csdo_dsqp_last_limit.argtypes = [H, PP(C.c_int32), PP(C.c_int32), PP(C.c_int64)]
         L.csdo_dsqp_estimate_work.argtypes = [PP(abi.Problem), C.c_int32, abi.c_double_p]
         L.csdo_validate.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                     C.c_double, C.POINTER(abi.Vehicle), C.c_double, C.POINTER(abi.Validation)]

@@ -91,6 +91,8 @@ struct csdo_handle_s {
   DevBuf prof;
   PinnedBuf stage_up, stage_down;   // page-locked staging of the packed inputs / outputs
   PinnedBuf bridge_up, bridge_down; // ... of the batched device bridge (csdo_preprocess_device_batch)
+  int limit_world = -1, limit_agent = -1;   // what the last CSDO_ELIMIT of an upload was about (csdo_dsqp_last_limit)
+  int64_t limit_bytes = 0;
   double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
   DeviceBatch dev{};
 };
@@ -180,6 +182,19 @@ static int build_groups(csdo_handle h) {
   return CSDO_OK;
 }
 
+// Packing and scattering use std::thread pools and growing vectors: a std::system_error (thread limit of the caller's cgroup) or
+// std::bad_alloc must not cross the C ABI.
+template <class F>
+static int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return CSDO_ENOMEM;
+  } catch (...) {
+    return CSDO_EDEVICE;
+  }
+}
+
 extern "C" {
 
 const char* csdo_backend_name(void) { return "hip-gfx950"; }
@@ -229,6 +244,14 @@ void csdo_dsqp_destroy(csdo_handle h) {
   delete h;
 }
 
+int csdo_dsqp_last_limit(csdo_handle h, int32_t* world, int32_t* agent, int64_t* lds_bytes_needed) {
+  if (!h) return CSDO_EINVAL;
+  if (world) *world = h->limit_world;
+  if (agent) *agent = h->limit_agent;
+  if (lds_bytes_needed) *lds_bytes_needed = h->limit_bytes;
+  return CSDO_OK;
+}
+
 int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double* est) {
   if (!worlds || n_worlds < 1 || !est) return CSDO_EINVAL;
   try {
@@ -244,10 +267,17 @@ int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double
   }
 }
 
+static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds);
+static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds);
 int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
+  return guarded([&]() { return upload_impl(h, worlds, n_worlds); });
+}
+static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
   if (!h) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   h->uploaded = false;
+  h->limit_world = h->limit_agent = -1;
+  h->limit_bytes = 0;
   const double t0 = now_s();
   int rc = pack_worlds(worlds, n_worlds, h->hb);
   if (rc != CSDO_OK) return rc;
@@ -255,7 +285,22 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   const size_t Na = hb.agents.size();
   if ((rc = build_groups(h)) != CSDO_OK) return rc;
   for (const LaunchGroup& g : h->groups)
-    if (g.lds_bytes > dsqp_lds_capacity()) return CSDO_ELIMIT;   // e.g. more obstacles than fit beside the exchange vectors
+    if (g.lds_bytes > dsqp_lds_capacity()) {   // e.g. more obstacles than fit beside the exchange vectors
+      // which world it is: csdo_dsqp_last_limit (one oversized world rejects the whole batch; the caller can drop it and retry)
+      h->limit_world = h->limit_agent = -1;
+      for (int i = 0; i < g.count && h->limit_world < 0; ++i) {
+        const int a = h->order[g.first + i];
+        const AgentDesc& ad = hb.agents[a];
+        int mode = 0, rows = 0;
+        dsqp_agent_class(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, &mode, &rows);
+        if (dsqp_lds_bytes(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, mode, false) > dsqp_lds_capacity()) {
+          h->limit_world = ad.world;
+          h->limit_agent = a - hb.world_first_agent[ad.world];
+          h->limit_bytes = (int64_t)dsqp_lds_bytes(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, mode, false);
+        }
+      }
+      return CSDO_ELIMIT;
+    }
   const double t1 = now_s();
   // stage everything in one page-locked arena (256-byte aligned slots), then one asynchronous copy per array
   struct Item { DevBuf* buf; const void* src; size_t bytes; size_t off; };
@@ -469,6 +514,9 @@ void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles) {
 }
 
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
+  return guarded([&]() { return download_impl(h, results, n_worlds); });
+}
+static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds) {
   if (!h || !h->uploaded || !results || n_worlds != h->n_worlds) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   const HostBatch& hb = h->hb;
@@ -569,6 +617,7 @@ int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* a
   const int Nt = C.Nt;
   const size_t NN = (size_t)Na * Nt;
   auto fail = [&](int code) {
+    (void)hipStreamSynchronize(h->stream);   // copies enqueued from C's (pageable, local) vectors may still be reading them
     bridge_free(out);
     return code;
   };
@@ -609,7 +658,7 @@ int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* a
         hipStreamSynchronize(s) != hipSuccess)
       return fail(CSDO_EDEVICE);
   }
-  if ((rc = bridge_planes(C, pairs, veh, coef.data(), out)) != CSDO_OK) return rc;
+  if ((rc = bridge_planes(C, pairs, veh, coef.data(), out)) != CSDO_OK) return fail(rc);   // (releases x0_bar as well)
   out->initial_inter_legal = collide ? 0 : 1;
   return CSDO_OK;
 }

@@ -66,6 +66,12 @@ class DsqpHandle:
     def set_min_residency_mode(self, mode):
         check(lib().csdo_dsqp_set_min_residency_mode(self._h, int(mode)), "csdo_dsqp_set_min_residency_mode")
 
+    def last_limit(self):
+        """(world, agent, lds_bytes_needed) of the last CSDO_ELIMIT of an upload (csdo_dsqp_last_limit); world = -1 if none."""
+        w, a, b = C.c_int32(), C.c_int32(), C.c_int64()
+        check(lib().csdo_dsqp_last_limit(self._h, C.byref(w), C.byref(a), C.byref(b)), "csdo_dsqp_last_limit")
+        return int(w.value), int(a.value), int(b.value)
+
     def launch_groups(self):
         """How the uploaded batch is launched (csdo_dsqp_launch_groups): a list of dicts, one per concurrent kernel."""
         buf = (abi.LaunchGroup * 8)()

@@ -193,6 +193,44 @@ def test_gpu_error_codes(gpu_handle, veh_parm):
     assert _lib.lib().csdo_dsqp_solve(gpu_handle._h, C.byref(p), C.byref(sol._c)) == abi.CSDO_EINVAL  # Nt < 2
 
 
+@pytest.mark.parametrize("Nt,per_lane", [(100, 46), (200, 46), (300, 30)])
+def test_obstacle_count_at_which_a_world_no_longer_fits(gpu_handle, veh_parm, Nt, per_lane):
+    """CSDO_ELIMIT at upload: the obstacle list is staged in LDS beside the per-timestep arrays of the leanest residency mode of
+    the agent's class (512 threads: mode 1, 46 doubles per timestep; 1024 threads: mode 3, 30), the tail (1472 doubles) and
+    nothing else.  The largest obstacle count that fits is pinned here for three horizons; one world beyond it rejects the
+    whole batch, nothing is launched, and csdo_dsqp_last_limit says which world it was."""
+    from csdotrajectoryplanning_amd import _lib
+    from csdotrajectoryplanning_amd.problem import World
+    veh, parm = veh_parm
+    st = (Nt + 1) & ~1
+    cap = 160 * 1024 - 64
+    fixed = (per_lane * st + 32 + 72 + 36 * 38) * 8
+    n_fit = (cap - fixed) // 8 // 3 + 2
+    while ((3 * n_fit + 1) & ~1) * 8 + fixed > cap:        # (the staged list is padded to an even number of doubles)
+        n_fit -= 1
+    assert {100: 4800, 200: 3266, 300: 3333}[Nt] == n_fit      # the capability, in numbers
+
+    def world(n_obs):
+        x0 = np.zeros((1, Nt, 6))
+        x0[0, :, 0] = 5.0 + 0.3 * np.arange(Nt)
+        x0[0, :, 1] = 5.0
+        x0[0, :-1, 4] = 0.3 / parm.dt
+        obs = np.column_stack([np.full(n_obs, 90.0), np.full(n_obs, 190.0), np.full(n_obs, 0.1)])
+        return World(x0, np.zeros(2, np.int32), np.zeros(0, abi_plane()), 100.0 + 0.3 * Nt, 200.0, obs, veh, parm)
+
+    gpu_handle.upload([world(10), world(n_fit)])            # fits: the upload succeeds
+    assert gpu_handle.last_limit()[0] == -1
+    with pytest.raises(_lib.CsdoError, match="limit"):
+        gpu_handle.upload([world(10), world(n_fit + 2), world(5)])
+    w_, a_, need = gpu_handle.last_limit()
+    assert (w_, a_) == (1, 0) and need > cap
+
+
+def abi_plane():
+    from csdotrajectoryplanning_amd import abi
+    return abi.PLANE_DTYPE
+
+
 def test_solver_dsqp_mirror(oracle, veh_parm):
     """The host-side mirror keeps the reference's constructor-solves shape (sqp/dsqp_solver.h:24-47)."""
     from csdotrajectoryplanning_amd.solver import SolverDSQP

@@ -47,6 +47,23 @@ struct SolutionStatistics {        // sqp/common.h:25-36 defaults: the floats -1
   int search_status = 2, solver_status = 0;
 };
 
+// The reference's statistics for a DO-phase result, its semantics (csdo.cc:98-161, sqp/dsqp_solver.cc:1194-1248) on this
+// backend's clocks: rt_optimization = wall clock of the call; rt_max_optimization ("ideal parallel") = slowest agent's device time
+// (its corridors included) + everything outside the kernels; runtime = search + preprocess + that; search_status 1 when the initial
+// guess was not statically legal (csdo.cc:152-154).
+inline SolutionStatistics statistics_from(const csdo_result& r, double rt_search, double rt_preprocess, int search_status = 2) {
+  SolutionStatistics s;
+  const double other = r.t_total > r.t_device ? r.t_total - r.t_device : 0.0;
+  s.rt_search = rt_search;
+  s.rt_preprocess = rt_preprocess;
+  s.rt_optimization = r.t_total;
+  s.rt_max_optimization = r.t_max_individual + other;
+  s.runtime = (rt_search >= 0 && rt_preprocess >= 0) ? rt_search + rt_preprocess + s.rt_max_optimization : -1.0;
+  s.search_status = r.initial_static_legal ? search_status : 1;
+  s.solver_status = r.solver_status;
+  return s;
+}
+
 namespace detail {
 inline std::string strip_comment(const std::string& s) {   // `#` at the start of the line or after white space
   for (size_t i = 0; i < s.size(); ++i)

@@ -51,6 +51,28 @@ def write_solutions(path, solutions, stats=None):
         f.write("\n".join(out) + "\n")
 
 
+def solution_statistics(sol, rt_search=-1.0, rt_preprocess=-1.0, search_status=2):
+    """The reference's SolutionStatistics (sqp/common.h:25-36) for a DO-phase result, with the reference's semantics
+    (csdo.cc:98-161, sqp/dsqp_solver.cc:1194-1248) mapped onto this backend's clocks:
+      runtime_optimization                  wall clock of the SolverDSQP construction = `sol.t_total` (upload + kernels + download)
+      runtime_decentralized_optimization    "ideal parallel" time: the slowest agent + everything outside the per-agent loop.  The
+                                            reference adds the slowest agent's SQP time, the shared overhead and the slowest agent's
+                                            initial-corridor time; here an agent's device time already contains its corridors, so it
+                                            is `t_max_individual + (t_total - t_device)`
+      runtime                               runtime_search + runtime_preprocess + runtime_decentralized_optimization (csdo.cc:160-161)
+      search_status                         lowered to 1 ("minor collision") when the initial guess was not statically legal (csdo.cc:152-154)
+    cost / makespan / flowtime stay -1 as in csdo runs.  Returns the dict write_solutions takes."""
+    other = max(float(sol.t_total) - float(sol.t_device), 0.0)
+    rt_max = float(sol.t_max_individual) + other
+    if not sol.initial_static_legal:
+        search_status = 1
+    known = [t for t in (rt_search, rt_preprocess) if t >= 0]
+    return {"runtime": (sum(known) + rt_max) if len(known) == 2 else -1.0, "runtime_search": rt_search,
+            "runtime_preprocess": rt_preprocess, "runtime_optimization": float(sol.t_total),
+            "runtime_decentralized_optimization": rt_max, "search_status": int(search_status),
+            "solver_status": int(sol.solver_status)}
+
+
 def output_paths(output_file):
     """(result, guesses, corridors) file names as csdo.cc:76,139,164 derives them: the output file must end in `.yaml`;
     the prefix is everything but those five characters."""

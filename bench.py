@@ -549,8 +549,13 @@ def main():
     h.close()
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0:       # the ONE line, after everything that may write to stdout on its own (RCCL prints a banner)
+    if rank == 0:       # the ONE line, LAST: RCCL leaves a version banner in C stdio's buffer, which would otherwise come out at exit
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(line, flush=True)
 
 

@@ -343,6 +343,7 @@ def main():
         whole = [i for i in range(len(worlds)) if worlds[i].Na == len(infos[i]["paths"][2]) - 1]
         h.interpolate_and_planes_batch(items[:2], w0.veh, w0.parm)      # (first call: device buffers, page-locked staging)
         best = None
+        out_e2e = None                       # steady state: the caller's output arrays are reused from call to call
         for _ in range(3):
             t_b0 = time.perf_counter()
             bridged = h.interpolate_and_planes_batch(items, w0.veh, w0.parm)
@@ -357,7 +358,7 @@ def main():
             t_k = h.run(stream)
             t_kw = time.perf_counter() - t_k0
             t_d0 = time.perf_counter()
-            h.download()
+            out_e2e = h.download(out=out_e2e)
             t_dl = time.perf_counter() - t_d0
             tot = time.perf_counter() - t_b0
             if best is None or tot < best[0]:

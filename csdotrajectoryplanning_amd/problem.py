@@ -94,6 +94,40 @@ class Solution:
         return self
 
 
+class _BridgeMemory:
+    """Keeps a csdo_bridge_out (library-owned memory) alive for the numpy views built over it and releases it with them."""
+
+    def __init__(self, bo, free):
+        self.bo, self._free = bo, free
+
+    def __del__(self):
+        try:
+            self._free(C.byref(self.bo))
+        except Exception:
+            pass
+
+
+def bridge_views(bo: abi.BridgeOut, free, inst_dimx, inst_dimy, obstacles, veh, parm):
+    """(World, pairs, initial_inter_legal) as VIEWS of the library-owned csdo_bridge_out: no copy of x0_bar, planes or pairs (29 MB
+    for the 60 worlds of the map100 set).  Every array (and every slice of it, World.subset included) keeps the owner of the memory
+    alive; it is released (`free` = csdo_bridge_free) when the last one goes."""
+    Na, Nt = bo.Na, bo.Nt
+    keep = _BridgeMemory(abi.BridgeOut.from_buffer_copy(bytes(bo)), free)
+
+    def view(ptr, n_items, dtype):
+        if n_items == 0:
+            return np.zeros(0, dtype=dtype)
+        raw = (C.c_char * (n_items * np.dtype(dtype).itemsize)).from_address(C.cast(ptr, C.c_void_p).value)
+        raw._keep = keep                      # the buffer object is the base of every numpy view taken from it
+        return np.frombuffer(raw, dtype=dtype)
+
+    x0 = view(bo.x0_bar, Na * Nt * 6, np.float64).reshape(Na, Nt, 6)
+    po = view(bo.plane_off, Na + 1, np.int32)
+    planes = view(bo.planes, int(po[-1]), abi.PLANE_DTYPE)
+    pairs = view(bo.pairs, 3 * bo.n_pairs, np.int32).reshape(-1, 3)
+    return World(x0, po, planes, inst_dimx, inst_dimy, obstacles, veh, parm), pairs, int(bo.initial_inter_legal)
+
+
 def bridge_to_world(bo: abi.BridgeOut, inst_dimx, inst_dimy, obstacles, veh, parm):
     """Copy a csdo_bridge_out (library-owned memory) into numpy arrays; returns (World, pairs, initial_inter_legal)."""
     Na, Nt = bo.Na, bo.Nt

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import abi
 from ._lib import check, lib
-from .problem import Solution, World, bridge_to_world
+from .problem import Solution, World, bridge_to_world, bridge_views
 
 
 class DsqpHandle:
@@ -87,9 +87,11 @@ class DsqpHandle:
         check(lib().csdo_dsqp_agent_groups(self._h, abi.as_int32_p(out), n), "csdo_dsqp_agent_groups")
         return out
 
-    def download(self):
+    def download(self, out=None):
+        """Results of the last run.  out: the list a previous download of the same batch returned - its arrays are written again
+        instead of allocating (and first touching) new ones."""
         worlds = self._keep
-        sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
+        sols = out if out is not None else [Solution.allocate(w.Na, w.Nt) for w in worlds]
         res = (abi.Result * len(worlds))(*[s._c for s in sols])
         check(lib().csdo_dsqp_download(self._h, res, len(worlds)), "csdo_dsqp_download")
         for s, r in zip(sols, res):
@@ -135,11 +137,8 @@ class DsqpHandle:
         outs = (abi.BridgeOut * n)()
         check(lib().csdo_preprocess_device_batch(self._h, n, st_p, ac_p, po_p, abi.as_int32_p(na), g_p, C.byref(veh),
                                                  C.byref(parm), outs), "csdo_preprocess_device_batch")
-        res = []
-        for k, it in enumerate(items):
-            res.append(bridge_to_world(outs[k], it[4], it[5], it[6], veh, parm))
-            lib().csdo_bridge_free(C.byref(outs[k]))
-        return res
+        # views of the library-owned results (released with them): no second copy of 29 MB of planes on the way to the upload
+        return [bridge_views(outs[k], lib().csdo_bridge_free, it[4], it[5], it[6], veh, parm) for k, it in enumerate(items)]
 
     def validate(self, solutions, veh, obstacles=None, dimx=0.0, dimy=0.0, margin=0.0, frames_per_move=None):
         """Trajectory validator on this GPU (csdo_validate; with frames_per_move = S >= 1 csdo_validate_frames: the frames

@@ -92,7 +92,8 @@ def test_first_qp_in_the_regimes_the_baseline_sets_do_not_reach(gpu_handle, orac
     d, dc, same = _per_agent(got, ref)
     assert same.all(), np.nonzero(~same)[0]
     assert d.max() <= FIRST_QP_TOL and np.median(d) < 1e-8, (float(d.max()), float(np.median(d)))
-    assert max(float(np.abs(g.corridors - r.corridors).max()) for g, r in zip(got, ref)) == 0.0     # initial boxes: bit for bit
+    # (the boxes returned are the ones refreshed at the QP's solution, corridor.cc via dsqp_solver.cc:251-253: they follow it)
+    assert max(float(np.abs(g.corridors - r.corridors).max()) for g, r in zip(got, ref)) <= 1e-6
     for g, r in zip(got, ref):
         assert g.initial_static_legal == r.initial_static_legal
     if workload == "agents100":

@@ -596,8 +596,17 @@ CSDO_FN int first_step(const int d, const double xc, const double yc, const doub
   return (g < 0.0) ? 0 : (int)fl + 1;
 }
 
+// The four step counts of an obstacle (one per side, each <= GROW_NEVER < 256) do not change from pass to pass: the first pass
+// packs them into one word per culled obstacle, the other three read them back instead of running first_step twelve more times
+// per obstacle (the corridor phase is the one phase that is bound by instruction issue: both roles grow boxes at once).  The words
+// live in whatever memory the caller has idle - the agent program: the ADMM block's LDS arrays, entry j of thread i at
+// base[j * stride + i] (conflict free) -; obstacles beyond `cap` are recomputed.  cap = 0: no cache.
+struct BoxCache {
+  unsigned* base;
+  int stride, cap;
+};
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
-                      BoxD& res) {
+                      BoxD& res, const BoxCache& ec) {
   const double ds = 0.1;
   const ObsMask M = cull_obstacles(xc, yc, obs, n_obs, rv);
 #if defined(CSDO_GROW_STATS)
@@ -633,6 +642,7 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
     if (moving & 8u) best = 4 * stop3 + 3 < best ? 4 * stop3 + 3 : best;
     unsigned long long m0 = M.m[0], m1 = M.m[1], m2 = M.m[2], m3 = M.m[3];
     int k_tail = OBS_MASK_CAP;
+    int j_ = 0;   // position of the obstacle in this (deterministic) order: its slot in the cache
     while ((m0 | m1 | m2 | m3) != 0ull || k_tail < n_obs) {
       int k;
       if (m0) {
@@ -650,16 +660,28 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
       } else {
         k = k_tail++;
       }
-      const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
       // the stopped sides must have their inequality true where they stopped; among the moving ones the obstacle is entered
       // in round mx by the last side that attains it
       bool live = true;
       int mx = 0, last = 0;
+      unsigned packed = 0u;
+      const bool cached = j_ < ec.cap;
+      if (cached && pass > 0) {
+        packed = ec.base[(size_t)j_ * (size_t)ec.stride];
+      } else {
+        const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
+#if defined(CSDO_LANE_MODE_DEVICE)
+#pragma nounroll
+#endif
+        for (int d = 0; d < 4; ++d) packed |= (unsigned)first_step(d, xc, yc, ox, oy, infl) << (8 * d);
+        if (cached) ec.base[(size_t)j_ * (size_t)ec.stride] = packed;
+      }
+      ++j_;
 #if defined(CSDO_LANE_MODE_DEVICE)
 #pragma nounroll
 #endif
       for (int d = 0; d < 4; ++d) {
-        const int e = first_step(d, xc, yc, ox, oy, infl);
+        const int e = (int)((packed >> (8 * d)) & 0xffu);
         const int stopped_at = (d == 0) ? st0 : (d == 1) ? st1 : (d == 2) ? st2 : st3;
         if (moving & (1u << d)) {
           if (e >= mx) {
@@ -701,7 +723,7 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
 // 2 inside an inflated obstacle).  First colliding obstacle = lowest input index (documented deviation from the
 // reference's unordered_set iteration order).
 CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double dimx, double dimy, double rv,
-                     BoxD& res) {
+                     BoxD& res, const BoxCache& ec = BoxCache{nullptr, 0, 0}) {
 #if defined(CSDO_ABL_NOBOX)   // allocation experiment only
   res = BoxD{x - 1.0, y - 1.0, x + 1.0, y + 1.0};
   return 1;
@@ -747,7 +769,7 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
       in_map = x > rv && x < dimx - rv && y > rv && y < dimy - rv;
     }
     if (in_map) {
-      const bool grew = grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand);
+      const bool grew = grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand, ec);
       if (hit >= 0) {
         ObsMask all;
         all.m[0] = all.m[1] = all.m[2] = all.m[3] = ~0ull;   // isBoxValid over every obstacle (bits >= n_obs masked below)

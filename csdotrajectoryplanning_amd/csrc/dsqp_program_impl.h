@@ -585,6 +585,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   }
   CSDO_SYNC();
 
+  constexpr int n_block_fields = (MODE == 3 ? 30 : (MODE == 1 ? 46 : LD_block));
+  // grow_box's per-obstacle step counts (BoxCache): the ADMM block's LDS arrays are idle whenever boxes are grown
+#if defined(CSDO_LANE_MODE_DEVICE)
+  // (all but the last two fields of them: those carry the initial boxes' status flags, written while other lanes still grow)
+  const int box_cap_ = (int)(((size_t)(n_block_fields - 2) * (size_t)sh.stride * 2) / (size_t)blockDim.x);
+  const BoxCache box_cache{(unsigned*)sh.vec + threadIdx.x, (int)blockDim.x, box_cap_ < 32 ? box_cap_ : 32};
+#else
+  unsigned box_words_[32];
+  const BoxCache box_cache{box_words_, 1, 32};
+#endif
   CSDO_PHASE(1);
   // ---------------------------------------------------------------- initial corridors (calcCorridors :164-248)
   // State's disc centres are float members (motion_planning.h:115-118,229-230): round through float here.
@@ -592,25 +602,25 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
     const double xr = (double)(float)(px + P.r2x * cos(pyaw)), yr = (double)(float)(py + P.r2x * sin(pyaw));
     BoxD br;
-    const int sr = make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br);
+    const int sr = make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
     CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
     CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
-    SH(carry2, 5, t) = ((sr >> 1) > 0) ? 1.0 : 0.0;
+    SU(n_block_fields - 1, t) = ((sr >> 1) > 0) ? 1.0 : 0.0;
   }
   double my_flag = 0.0;
   CSDO_LANES(t) {   // front disc on the row lane
     const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
     const double xf = (double)(float)(px + P.f2x * cos(pyaw)), yf = (double)(float)(py + P.f2x * sin(pyaw));
     BoxD bf;
-    const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+    const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
     CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
     CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
-    SH(carry2, 4, t) = ((sf >> 1) > 0) ? 1.0 : 0.0;
+    SU(n_block_fields - 2, t) = ((sf >> 1) > 0) ? 1.0 : 0.0;
   }
   (void)my_flag;
   CSDO_SYNC();
   CSDO_LANES(t) {
-    const double part[1] = {dmax(SH(carry2, 4, t), SH(carry2, 5, t))};
+    const double part[1] = {dmax(SU(n_block_fields - 2, t), SU(n_block_fields - 1, t))};
     red_put<1>(sh, t, part);
   }
   {
@@ -1771,7 +1781,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
         const double xr = px + P.r2x * cos(pyaw), yr = py + P.r2x * sin(pyaw);
         BoxD br;
-        make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br);
+        make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
         CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
         CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
       }
@@ -1781,7 +1791,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
         const double xf = px + P.f2x * cos(pyaw), yf = py + P.f2x * sin(pyaw);
         BoxD bf;
-        make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf);
+        make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
         CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
         CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
       }

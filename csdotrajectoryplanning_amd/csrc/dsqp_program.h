@@ -54,6 +54,16 @@ __device__ __forceinline__ double csdo_keep_f64(double v) {   // the same for a 
   asm volatile("" : "+v"(v));
   return v;
 }
+// c ? 1.0 : d, selected on the two halves with literal operands.  As a select of doubles the constant 1.0 is hoisted into a
+// register pair for the whole kernel, spilled, and reloaded from scratch - with a full wait - in front of every use: the
+// sixteen row factors of a Ruiz pass were sixteen scratch round trips in a row.
+__device__ __forceinline__ double csdo_one_if(const bool c, const double d) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  unsigned one_hi;   // (a literal in the source is put back together with the other half into that very select, or shares the register)
+  asm volatile("s_mov_b32 %0, 0x3ff00000" : "=s"(one_hi));
+  const unsigned lo = c ? 0u : (unsigned)u, hi = c ? one_hi : (unsigned)(u >> 32);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = csdo_opaque((int)threadIdx.x); t < Nt)
 // ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
 #define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
@@ -106,6 +116,7 @@ __device__ __forceinline__ double csdo_keep_f64(double v) {   // the same for a 
 #define csdo_keep(v) (v)
 #define csdo_keep_f64(v) (v)
 #define csdo_opaque_s(v) (v)
+#define csdo_one_if(c, d) ((c) ? 1.0 : (d))
 #define CSDO_FN inline
 #define CSDO_NOINLINE inline
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) for (int t = 0; t < Nt; ++t)
@@ -209,7 +220,7 @@ CSDO_FN int osqp_min_i(int a, int b) { return (a < b) ? a : b; }
 CSDO_FN double hot_max(double a, double b) { return __builtin_fmax(a, b); }
 CSDO_FN double hot_min(double a, double b) { return __builtin_fmin(a, b); }
 CSDO_FN double limit_scaling(double d) {
-  d = d < MIN_SCALING ? 1.0 : d;
+  d = csdo_one_if(d < MIN_SCALING, d);
   d = d > MAX_SCALING ? MAX_SCALING : d;
   return d;
 }
@@ -217,7 +228,7 @@ CSDO_FN double limit_scaling(double d) {
 CSDO_FN double nmax(double a, double b) { return __builtin_fmax(a, b); }
 // limit_scaling of such a maximum (d >= 0, never NaN): the upper clamp as one v_min_f64
 CSDO_FN double limit_norm(double d) {
-  d = d < MIN_SCALING ? 1.0 : d;
+  d = csdo_one_if(d < MIN_SCALING, d);
   return __builtin_fmin(d, MAX_SCALING);
 }
 CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
@@ -244,7 +255,6 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   double y[NROW], z[NROW];  // ADMM dual / slack (z doubles as Ruiz scratch before the warm start)
   double x[6];              // scaled primal iterate
   double b[6];              // Ruiz scratch / rhs temporary
-  double dsc[6];            // accumulated Ruiz column scaling D (set-up stage; kept in the workspace afterwards)
   double Pvv, Pww, Pvn;     // scaled objective (set-up stage; kept in the workspace afterwards)
   unsigned eqmask;          // rows in OSQP's "equality" class (rho * 1e3)
   unsigned loosemask;       // rows with both bounds infinite (rho = RHO_MIN)

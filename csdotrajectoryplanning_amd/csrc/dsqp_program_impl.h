@@ -665,7 +665,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       SU(14, t) = dfx; SU(15, t) = dfy; SU(16, t) = drx; SU(17, t) = dry;
       SU(18, t) = exf; SU(19, t) = eyf; SU(20, t) = exr; SU(21, t) = eyr;
       SU(10, t) = 0.0; SU(11, t) = 0.0; SU(12, t) = 0.0;
-      CSDO_FOR(j, 6, { S.dsc[j] = 1.0; });
+      // the accumulated column scaling D lives in the workspace (six accumulators less in the registers of the passes)
+      CSDO_FOR(j, 6, { CD(C_D + j, t) = 1.0; });
       // the (unscaled) bounds wait in the workspace until the warm start: 32 doubles less in the equilibration's registers
       CSDO_FOR(i, NROW, {
         WS(W_LO + i, t) = S.lo[i];
@@ -738,6 +739,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
         double cn_[6] = {0, 0, 0, 0, 0, 0};  // column norms of [P; A]
+        double dacc[6];                      // accumulated column scaling so far (fetched early: the row factors hide the trip)
+        CSDO_FOR(j, 6, { dacc[j] = CD(C_D + j, t); });
         double* Dt = S.b;                    // scratch: per-column factor of this pass
         double* Et = S.z;                    // scratch: per-row factor of this pass
         if (t > 0) {
@@ -758,13 +761,20 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             });
             if constexpr (i < 4) rn = nmax(rn, fabs(S.cn[i]));
           }
-          Et[i] = 1.0 / sqrt(limit_norm(rn));
+          // the row's factor is applied to its own-column coefficients and folded into E at once (the column factors follow
+          // below, when the column maxima are complete): only the four kinematic rows' factors outlive this statement
+          const double e = 1.0 / sqrt(limit_norm(rn));
+          if constexpr (i < 4) Et[i] = e;
+          CSDO_FOR(s, 3, {
+            if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * e;
+          });
+          SU(14 + i, t) = csdo_one_if(pass == 0, SU(14 + i, t)) * e;   // (no branch between the rows: their square roots interleave)
         });
         CSDO_FOR(k, 3, {   // the timestep's inter-vehicle rows; cleared for the next pass
           cn_[k] = nmax(cn_[k], SU(10 + k, t));
           SU(10 + k, t) = 0.0;
         });
-        CSDO_FOR(j, 6, { Dt[j] = (j < S.ncols) ? 1.0 / sqrt(limit_norm(cn_[j])) : 1.0; });
+        CSDO_FOR(j, 6, { Dt[j] = csdo_one_if(j >= S.ncols, 1.0 / sqrt(limit_norm(cn_[j]))); });
         CSDO_FOR(k, 5, { SU(5 + k, t) = Dt[k]; });
         if (t == 0) sh.bcast[30 + ((pass + 1) & 1)] = 0.0;   // the other pass parity's cost-scaling flag
         // everything that only needs the lane's own factors is scaled right here; what needs the right neighbour's column
@@ -772,13 +782,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // factors and the lane's six column factors stay live across it
         CSDO_FOR(i, NROW, {
           CSDO_FOR(s, 3, {
-            if constexpr (row_col(i, s) >= 0) S.c[i][s] = (S.c[i][s] * Et[i]) * Dt[row_col(i, s)];
+            if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * Dt[row_col(i, s)];
           });
-          SU(14 + i, t) = (pass == 0) ? Et[i] : SU(14 + i, t) * Et[i];
         });
         S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
         S.Pww = (S.Pww * Dt[5]) * Dt[5];
-        CSDO_FOR(j, 6, { S.dsc[j] = S.dsc[j] * Dt[j]; });
+        CSDO_FOR(j, 6, { CD(C_D + j, t) = dacc[j] * Dt[j]; });
       }
       CSDO_SYNC();
       CSDO_SUB(1);
@@ -863,8 +872,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       WS(W_LOOSE, t) = (double)loose;
       // osqp_warm_start_x: x <- Dinv x0
       CSDO_FOR(j, 6, {
-        CD(C_D + j, t) = S.dsc[j];
-        S.x[j] = (1.0 / S.dsc[j]) * CD(C_SOL0 + j, t);
+        S.x[j] = (1.0 / CD(C_D + j, t)) * CD(C_SOL0 + j, t);
       });
       CSDO_FOR(k, 4, { SU(5 + k, t) = S.x[k]; });
     }
@@ -1011,6 +1019,39 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_PHASE(21);
       CSDO_SYNC();
       CSDO_PHASE(22);
+#if defined(CSDO_LANE_MODE_DEVICE)
+      // The product of the explicit tail inverse with the gathered rhs runs on the ROW waves, which have nothing else to do
+      // between these two barriers: three lanes per row of the inverse, each with two of the row's six accumulation chains
+      // (entry j of a row belongs to chain j mod 6, as in the one-lane-per-row form below: same operations in the same order,
+      // same bits), joined by two shuffles.  One lane per row was 36 LDS round trips and FMAs deep: 1.5 k cycles of every iteration.
+      if constexpr (ROLE == ROLE_ROW) {
+        const int x = (int)threadIdx.x, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
+        if (x < 128) {
+          double a0 = 0.0, a1 = 0.0;
+          if (wl < 63 && r < n_tail) {
+            double tr0[6], tr1[6], tb0[6], tb1[6];
+            CSDO_FOR(j, 6, {
+              tr0[j] = SH(tinv, 6 * j + p2, r);
+              tr1[j] = SH(tinv, 6 * j + p2 + 1, r);
+              tb0[j] = sh.tvec[6 * j + p2];
+              tb1[j] = sh.tvec[6 * j + p2 + 1];
+            });
+            CSDO_FOR(j, 6, {
+              a0 = fma(tr0[j], tb0[j], a0);
+              a1 = fma(tr1[j], tb1[j], a1);
+            });
+          }
+          const double s01 = a0 + a1;                                   // lane 0 of the row: a0 + a1, lane 1: a2 + a3, lane 2: a4 + a5
+          const double s0123 = s01 + wave_shfl_down(s01, 1);            // lane 0: (a0 + a1) + (a2 + a3)
+          const double tot = s0123 + wave_shfl_down(s01, 2);            // lane 0: ... + (a4 + a5)
+          if (wl < 63 && r < n_tail && p2 == 0) {
+            const int kn = r / 6, i = r - 6 * kn;
+            sh.vec[(kn * h_tail) * LD_vec + i] = tot;
+          }
+        }
+      }
+      if constexpr (ROLE == ROLE_BOTH)
+#endif
       CSDO_TLANES_TOP(t) {
         {
           // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed

@@ -230,6 +230,100 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   CSDO_FPHASE(16);
   for (int h = 1; h < h_tail; h <<= 1) {
     const int m2 = 2 * h - 1;
+#define XC(k, tt) sh.vec[(size_t)(k) * csdo_opaque_s(sh.stride) + (unsigned)(tt)]
+    if constexpr (MODE == 0) {
+      // MODE 0, column-parallel: a level has one eliminated node in every aligned block of 2h lanes and the other lanes of the
+      // block are idle, so the node's five 6x6 products (900 FMAs deep on one lane, 13 k cycles per level with their loads) are
+      // dealt by COLUMNS to the first G = 2, 3, 6 lanes of the block (h = 1, 2, >= 4): every element is still the same chain of
+      // six FMAs - same bits.  The node's own lane inverts the pivot block first and shows it to the others through its LDS
+      // column (fields 36..56; 0..35 hold T = Sinv Rl, then V = Sinv Rr', each column owned by the lane that computes it).
+      // The exchange of a level goes through LDS: the ADMM block's per-timestep arrays (vec .. fx, 80 doubles per timestep,
+      // contiguous) are dead during the factorisation; seen as 80 fields x stride they give every node a column.  The products'
+      // Schur complements are DELIVERED into the columns of the two surviving neighbours: fields 0..20 <- U_r of the left
+      // neighbour, 21..41 <- U_l of the right neighbour, 42..77 <- the new coupling from the right neighbour.  (Through the
+      // workspace the absorption alone was 19 k cycles per level: the workspaces of the 32 agents of an XCD do not fit its L2.)
+      CSDO_SLANES(t) {
+        if ((t & m2) == h) {
+          double Sinv[21];
+          {
+            double Ain[21];
+            CSDO_FOR(k, 21, { Ain[k] = FA(k, t); });
+            spd_inverse6(Ain, Sinv);
+          }
+          CSDO_FOR(k, 21, {
+            WS(W_SINV + k, t) = Sinv[k];
+            XC(36 + k, t) = Sinv[k];
+          });
+        }
+      }
+      CSDO_SYNC();
+      const int G = (h == 1) ? 2 : ((h == 2) ? 3 : 6), per = 6 / G;
+      CSDO_STHREADS(l0, nthr) {
+        // The loops of this stage are marked cold: by their nesting depth alone the register allocator ranks them above the ADMM
+        // iterations and spills the solve's factor entries (122 ms against 73 ms per step).  For the same reason the operands
+        // are fetched where they are used (the pivot inverse: broadcast reads from the node's LDS column; the couplings: from the
+        // workspace): held in registers across the column loop they are spilled, or push the spills into the solve.
+        int l = l0;
+        do {   // (one trip unless the block's helper lanes reach past the solver threads)
+          const int base = l & ~m2, g = l - base, t = base + h;
+          if (g < G && t < Nt) {
+            const bool has_r = (t + h) < Nt;
+            const size_t st_ = (size_t)csdo_opaque_s(sh.stride);
+            const double* const sv_ = sh.vec + 36 * st_ + (unsigned)t;
+#define SV(k) sv_[(size_t)(k) * st_]
+            {
+              int cc = 0;
+              do {
+                const int c = g * per + cc;
+                double rlc[6], tc[6];
+                CSDO_FOR(k, 6, { rlc[k] = FR(k * 6 + c, base); });
+                CSDO_FOR(r, 6, {             // column c of T = Sinv Rl = F_l, what the solve uses
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(SV(sym(r, k)), rlc[k], a); });
+                  tc[r] = a;
+                });
+                CSDO_FOR(r, 6, {
+                  XC(r * 6 + c, t) = tc[r];
+                  FE(r * 6 + c, t) = tc[r];
+                });
+                CSDO_FOR(a_, 6, {            // column c of U_l = Rl' T (lower triangle)
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(FR(k * 6 + a_, base), tc[k], a); });
+                  if (a_ >= c) XC(21 + a_ * (a_ + 1) / 2 + c, base) = a;
+                });
+              } while (__builtin_expect(++cc < per, 0));
+            }
+            if (has_r) {
+              int cc = 0;
+              do {
+                const int c = g * per + cc;
+                double tc[6], rrc[6], vc[6];
+                CSDO_FOR(k, 6, { tc[k] = XC(k * 6 + c, t); });
+                CSDO_FOR(k, 6, { rrc[k] = FR(c * 6 + k, t); });
+                CSDO_FOR(a_, 6, {            // column c of the new coupling (right node <- left node) = -Rr T
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(FR(a_ * 6 + k, t), tc[k], a); });
+                  XC(42 + a_ * 6 + c, base) = -a;
+                });
+                CSDO_FOR(r, 6, {             // column c of V = Sinv Rr'; F_r = E_r Sinv = V'
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(SV(sym(r, k)), rrc[k], a); });
+                  vc[r] = a;
+                });
+                CSDO_FOR(r, 6, { XC(r * 6 + c, t) = vc[r]; });
+                CSDO_FOR(a_, 6, {            // column c of U_r = Rr V (lower triangle)
+                  double a = 0.0;
+                  CSDO_FOR(k, 6, { a = fma(FR(a_ * 6 + k, t), vc[k], a); });
+                  if (a_ >= c) XC(a_ * (a_ + 1) / 2 + c, t + h) = a;
+                });
+              } while (__builtin_expect(++cc < per, 0));
+            }
+#undef SV
+          }
+          l += nthr;
+        } while (__builtin_expect(l < Nt + 6, 0));
+      }
+    } else
     CSDO_SLANES(t) {  // eliminated nodes
       if ((t & m2) == h) {
         const bool has_r = (t + h) < Nt;
@@ -252,7 +346,6 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           // neighbour, 21..41 <- U_l of the right neighbour, 42..77 <- the new coupling from the right neighbour.  (Through
           // the workspace the absorption alone was 19 k cycles per level: the workspaces of the 32 agents of an XCD do not
           // fit its L2, so the exchange went to HBM and back.)
-#define XC(k, tt) sh.vec[(size_t)(k) * csdo_opaque_s(sh.stride) + (unsigned)(tt)]
 #define STASH(k) (*((MODE == 0) ? &XC(k, t) : &SH(stash, k, t)))
 #define PUT_UL(idx, v) (*((MODE == 0) ? &XC(21 + (idx), t - h) : &SX(idx, t)) = (v))
 #define PUT_CPL(idx, v) (*((MODE == 0) ? &XC(42 + (idx), t - h) : &SX(42 + (idx), t)) = (v))
@@ -381,6 +474,9 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     CSDO_SYNC();
     CSDO_FPHASE(19);
     CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements and take the coupling to their new right neighbour
+      if constexpr (MODE == 0) {   // (beside them, the eliminated nodes move F_r = V' from their LDS column to its place)
+        if ((t & m2) == h && (t + h) < Nt) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = XC(r * 6 + c, t); }); });
+      }
       if ((t & m2) == 0) {
         double A[21];
         CSDO_FOR(k, 21, { A[k] = FA(k, t); });

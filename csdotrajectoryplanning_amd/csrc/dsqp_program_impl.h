@@ -1693,11 +1693,28 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           double r6[6];
           CSDO_FOR(j, 6, { r6[j] = SH(rhs, j, t); });
           if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
-          if (rows_lds) {
-            for (int p = V.ts0; p < V.ts1; ++p) CSDO_FOR(k, 3, { r6[k] += PC_L(k, p); });
-          } else {
-            for (int p = V.ts0; p < V.ts1; ++p) CSDO_FOR(k, 3, { r6[k] += PC_G(k, p); });
-          }
+          // the planes' shares, three planes per round trip (added one by one in the planes' order, as before: a timestep in a
+          // cluster of vehicles has several planes, and one LDS - or workspace - round trip per plane was the wave's critical path)
+          auto add_planes = [&](auto lds_c) __attribute__((always_inline)) {
+            constexpr bool L = decltype(lds_c)::value;
+            const int pe = V.ts1;
+            for (int p = V.ts0; p < pe; p += 3) {
+              double v[3][3];
+              CSDO_FOR(q, 3, {
+                const int pq = (p + q < pe) ? p + q : p;
+                CSDO_FOR(k, 3, { v[q][k] = L ? PC_L(k, pq) : PC_G(k, pq); });
+              });
+              CSDO_FOR(q, 3, {
+                const bool ok = (p + q) < pe;
+                CSDO_FOR(k, 3, {
+                  const double s_ = r6[k] + v[q][k];
+                  r6[k] = ok ? s_ : r6[k];
+                });
+              });
+            }
+          };
+          if (rows_lds) add_planes(std::true_type{});
+          else add_planes(std::false_type{});
           CSDO_FOR(j, 6, { V.b[j] = r6[j]; });
         }
         solve();

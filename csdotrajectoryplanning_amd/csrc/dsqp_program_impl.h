@@ -820,7 +820,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           lds_max_nonneg(&SU(11, tp), fb);
           lds_max_nonneg(&SU(12, tp), fc);
           const double rn = nmax(nmax(fa, fb), fc);
-          const double et = 1.0 / sqrt(limit_norm(rn));
+          const double et = inv_sqrt_limited(limit_norm(rn));
           RZ(r, 0, R_CA) = a * et;
           RZ(r, 1, R_CB) = bb * et;
           RZ(r, 2, R_CY) = cy * et;
@@ -845,32 +845,48 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         cn_[4] = nmax(cn_[4], nmax(fabs(S.Pvv), fabs(S.Pvn)));
         cn_[5] = nmax(cn_[5], fabs(S.Pww));
-        CSDO_FOR(i, NROW, {
-          double rn = 0.0;
-          if (S.act & (1u << i)) {
-            CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) {
-                const double a = fabs(S.c[i][s]);
-                rn = nmax(rn, a);
-                cn_[row_col(i, s)] = nmax(cn_[row_col(i, s)], a);
-              }
-            });
-            if constexpr (i < 4) rn = nmax(rn, fabs(S.cn[i]));
-          }
-          // the row's factor is applied to its own-column coefficients and folded into E at once (the column factors follow
-          // below, when the column maxima are complete): only the four kinematic rows' factors outlive this statement
-          const double e = 1.0 / sqrt(limit_norm(rn));
-          if constexpr (i < 4) Et[i] = e;
-          CSDO_FOR(s, 3, {
-            if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * e;
+        // Four rows at a time: their norms (with the selects of limit_norm, which are fenced), then the four reciprocal square
+        // roots in one stretch of plain arithmetic - four independent chains of 18 dependent fp64 instructions that the
+        // scheduler interleaves (row after row they ran at the latency of one chain: a lone wave per SIMD) -, then the factors
+        // are applied to the rows' own-column coefficients and folded into E (the column factors follow below, when the
+        // column maxima are complete): only the four kinematic rows' factors outlive their group.
+        CSDO_FOR(grp, NROW / 4, {
+          double ln[4], e4[4];
+          CSDO_FOR(q, 4, {
+            constexpr int i = 4 * grp + q;
+            double rn = 0.0;
+            if (S.act & (1u << i)) {
+              CSDO_FOR(s, 3, {
+                if constexpr (row_col(i, s) >= 0) {
+                  const double a = fabs(S.c[i][s]);
+                  rn = nmax(rn, a);
+                  cn_[row_col(i, s)] = nmax(cn_[row_col(i, s)], a);
+                }
+              });
+              if constexpr (i < 4) rn = nmax(rn, fabs(S.cn[i]));
+            }
+            ln[q] = limit_norm(rn);
           });
-          SU(14 + i, t) = csdo_one_if(pass == 0, SU(14 + i, t)) * e;   // (no branch between the rows: their square roots interleave)
+          CSDO_FOR(q, 4, { e4[q] = inv_sqrt_limited(ln[q]); });
+          CSDO_FOR(q, 4, {
+            constexpr int i = 4 * grp + q;
+            if constexpr (i < 4) Et[i] = e4[q];
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * e4[q];
+            });
+            SU(14 + i, t) = csdo_one_if(pass == 0, SU(14 + i, t)) * e4[q];
+          });
         });
         CSDO_FOR(k, 3, {   // the timestep's inter-vehicle rows; cleared for the next pass
           cn_[k] = nmax(cn_[k], SU(10 + k, t));
           SU(10 + k, t) = 0.0;
         });
-        CSDO_FOR(j, 6, { Dt[j] = csdo_one_if(j >= S.ncols, 1.0 / sqrt(limit_norm(cn_[j]))); });
+        {
+          double ln[6], r6[6];
+          CSDO_FOR(j, 6, { ln[j] = limit_norm(cn_[j]); });
+          CSDO_FOR(j, 6, { r6[j] = inv_sqrt_limited(ln[j]); });
+          CSDO_FOR(j, 6, { Dt[j] = csdo_one_if(j >= S.ncols, r6[j]); });
+        }
         CSDO_FOR(k, 5, { SU(5 + k, t) = Dt[k]; });
         if (t == 0) sh.bcast[30 + ((pass + 1) & 1)] = 0.0;   // the other pass parity's cost-scaling flag
         // everything that only needs the lane's own factors is scaled right here; what needs the right neighbour's column

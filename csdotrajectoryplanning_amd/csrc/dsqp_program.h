@@ -525,21 +525,42 @@ struct ObsMask {
 };
 constexpr int OBS_MASK_CAP = 256;
 
-CSDO_FN ObsMask cull_obstacles(double xc, double yc, const double* obs, int n_obs, double rv) {
+// One walk over the obstacles for both questions about a point: which obstacles can ever touch a box grown from it (the
+// mask), and - make_box's isPointCollision - the first obstacle whose inflated square contains it (`hit`, -1: none).  Four
+// obstacles per trip: their twelve LDS reads are in flight together (one obstacle per trip was an LDS round trip per obstacle and
+// walk, twice per box: the longest part of the corridor phase).
+CSDO_FN ObsMask cull_obstacles(double xc, double yc, const double* obs, int n_obs, double rv, int& hit) {
   ObsMask M;
   M.m[0] = M.m[1] = M.m[2] = M.m[3] = 0ull;
   const double reach = 10.1 + 0.5;
-  for (int k = 0; k < n_obs && k < OBS_MASK_CAP; ++k) {
-    const double infl = obs[2 * n_obs + k] + rv + reach;
-    const double dx = obs[k] - xc, dy = obs[n_obs + k] - yc;
-    if (dx > -infl && dx < infl && dy > -infl && dy < infl) {
-      const unsigned long long bit = 1ull << (k & 63);
-      if (k < 64) M.m[0] |= bit;
-      else if (k < 128) M.m[1] |= bit;
-      else if (k < 192) M.m[2] |= bit;
-      else M.m[3] |= bit;
+  int first = -1;
+  auto one = [&](const int k, const double ox, const double oy, const double r) __attribute__((always_inline)) {
+    const double infl0 = r + rv;
+    if (first < 0 && (xc - infl0) < ox && ox < (xc + infl0) && (yc - infl0) < oy && oy < (yc + infl0)) first = k;
+    if (k < OBS_MASK_CAP) {
+      const double infl = infl0 + reach;
+      const double dx = ox - xc, dy = oy - yc;
+      if (dx > -infl && dx < infl && dy > -infl && dy < infl) {
+        const unsigned long long bit = 1ull << (k & 63);
+        if (k < 64) M.m[0] |= bit;
+        else if (k < 128) M.m[1] |= bit;
+        else if (k < 192) M.m[2] |= bit;
+        else M.m[3] |= bit;
+      }
     }
+  };
+  int k = 0;
+  for (; k + 4 <= n_obs; k += 4) {
+    double ox[4], oy[4], r[4];
+    CSDO_FOR(q, 4, {
+      ox[q] = obs[k + q];
+      oy[q] = obs[n_obs + k + q];
+      r[q] = obs[2 * n_obs + k + q];
+    });
+    CSDO_FOR(q, 4, { one(k + q, ox[q], oy[q], r[q]); });
   }
+  for (; k < n_obs; ++k) one(k, obs[k], obs[n_obs + k], obs[2 * n_obs + k]);
+  hit = first;
   return M;
 }
 
@@ -643,9 +664,8 @@ struct BoxCache {
   int stride, cap;
 };
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
-                      BoxD& res, const BoxCache& ec) {
+                      BoxD& res, const BoxCache& ec, const ObsMask& M) {
   const double ds = 0.1;
-  const ObsMask M = cull_obstacles(xc, yc, obs, n_obs, rv);
 #if defined(CSDO_GROW_STATS)
   csdo_grow_stats[0]++;
 #endif
@@ -774,14 +794,8 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
     if (y0 < rv) y = rv + eps;
     else if (y0 > dimy - rv) y = dimy - rv - eps;
   }
-  int hit = -1;
-  for (int k = 0; k < n_obs; ++k) {  // isPointCollision
-    const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
-    if ((x - infl) < ox && ox < (x + infl) && (y - infl) < oy && oy < (y + infl)) {
-      hit = k;
-      break;
-    }
-  }
+  int hit = -1;   // isPointCollision, and the obstacles within reach of a box grown from the point, in one walk
+  ObsMask M = cull_obstacles(x, y, obs, n_obs, rv, hit);
   // One call site for the growth: from the point itself, or (generateLegalPoint, corridor.cc:84-122) from up to 20 points on
   // a circle around the obstacle the point is inside of, alternating sides, until a grown box is valid against every obstacle.
   bool success = false;
@@ -806,7 +820,11 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
       in_map = x > rv && x < dimx - rv && y > rv && y < dimy - rv;
     }
     if (in_map) {
-      const bool grew = grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand, ec);
+      if (hit >= 0) {   // (a point on the ring around the obstacle: its own neighbourhood)
+        int unused_;
+        M = cull_obstacles(x, y, obs, n_obs, rv, unused_);
+      }
+      const bool grew = grow_box(x, y, obs, n_obs, dimx, dimy, rv, cand, ec, M);
       if (hit >= 0) {
         ObsMask all;
         all.m[0] = all.m[1] = all.m[2] = all.m[3] = ~0ull;   // isBoxValid over every obstacle (bits >= n_obs masked below)

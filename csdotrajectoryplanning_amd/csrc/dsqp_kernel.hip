@@ -21,7 +21,7 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
   for (int k = (int)threadIdx.x; k < n_obs; k += (int)blockDim.x) {
     lds[k] = obs_aos[3 * k];
     lds[n_obs + k] = obs_aos[3 * k + 1];
-    lds[2 * n_obs + k] = obs_aos[3 * k + 2];
+    lds[2 * n_obs + k] = obs_aos[3 * k + 2] + rv;   // (make_box takes the radii inflated by the disc radius)
   }
   __syncthreads();
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);

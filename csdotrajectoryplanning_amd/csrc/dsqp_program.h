@@ -534,13 +534,14 @@ CSDO_FN ObsMask cull_obstacles(double xc, double yc, const double* obs, int n_ob
   M.m[0] = M.m[1] = M.m[2] = M.m[3] = 0ull;
   const double reach = 10.1 + 0.5;
   int first = -1;
-  auto one = [&](const int k, const double ox, const double oy, const double r) __attribute__((always_inline)) {
-    const double infl0 = r + rv;
-    if (first < 0 && (xc - infl0) < ox && ox < (xc + infl0) && (yc - infl0) < oy && oy < (yc + infl0)) first = k;
-    if (k < OBS_MASK_CAP) {
-      const double infl = infl0 + reach;
-      const double dx = ox - xc, dy = oy - yc;
-      if (dx > -infl && dx < infl && dy > -infl && dy < infl) {
+  auto one = [&](const int k, const double ox, const double oy, const double ri) __attribute__((always_inline)) {
+    // (ri = r_obs + rv, as staged.)  The point test only for obstacles that pass the - much wider - cull: five vector
+    // instructions per obstacle otherwise
+    const double infl = ri + reach;
+    const double dx = ox - xc, dy = oy - yc;
+    if (fabs(dx) < infl && fabs(dy) < infl) {   // == dx > -infl && dx < infl && dy > -infl && dy < infl
+      if (first < 0 && (xc - ri) < ox && ox < (xc + ri) && (yc - ri) < oy && oy < (yc + ri)) first = k;
+      if (k < OBS_MASK_CAP) {
         const unsigned long long bit = 1ull << (k & 63);
         if (k < 64) M.m[0] |= bit;
         else if (k < 128) M.m[1] |= bit;
@@ -565,7 +566,7 @@ CSDO_FN ObsMask cull_obstacles(double xc, double yc, const double* obs, int n_ob
 }
 
 CSDO_FN bool obstacle_in_box(const BoxD& b, const double* obs, int n_obs, int k, double rv) {
-  const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
+  const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k];   // (staged as r_obs + rv)
   return (b.x_min - infl) < ox && ox < (b.x_max + infl) && (b.y_min - infl) < oy && oy < (b.y_max + infl);
 }
 
@@ -726,7 +727,7 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
       if (cached && pass > 0) {
         packed = ec.base[(size_t)j_ * (size_t)ec.stride];
       } else {
-        const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k] + rv;
+        const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k];   // (staged as r_obs + rv)
 #if defined(CSDO_LANE_MODE_DEVICE)
 #pragma nounroll
 #endif
@@ -805,7 +806,7 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
     hx = obs[hit];
     hy = obs[n_obs + hit];
     theta0 = atan2(y - hy, x - hx);
-    d_ring = rv + obs[2 * n_obs + hit] + 0.2;
+    d_ring = obs[2 * n_obs + hit] + 0.2;   // (rv + r_obs) + 0.2: the radius is staged as r_obs + rv
   }
   const int n_try = (hit >= 0) ? 20 : 1;
   BoxD cand{x, y, x, y};

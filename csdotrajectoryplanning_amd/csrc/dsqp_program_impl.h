@@ -661,7 +661,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       const double* o = B.obstacles + (int64_t)(wd.obs_off + k) * 3;
       sh.obs[k] = o[0];
       sh.obs[n_obs + k] = o[1];
-      sh.obs[2 * n_obs + k] = o[2];
+      sh.obs[2 * n_obs + k] = o[2] + rv;   // every user needs the obstacle radius inflated by the disc radius
     }
     LaneState& S = CSDO_LS(t);
     CSDO_FOR(k, 6, {

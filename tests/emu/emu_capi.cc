@@ -141,7 +141,7 @@ extern "C" int csdo_emu_generate_boxes(const double* pts, int32_t n, const doubl
   for (int k = 0; k < n_obs; ++k) {
     soa[k] = obstacles[3 * k];
     soa[n_obs + k] = obstacles[3 * k + 1];
-    soa[2 * n_obs + k] = obstacles[3 * k + 2];
+    soa[2 * n_obs + k] = obstacles[3 * k + 2] + veh->rv;   // (make_box takes the radii inflated by the disc radius)
   }
   for (int i = 0; i < n; ++i) {
     BoxD b{0, 0, 0, 0};

@@ -82,6 +82,27 @@ def test_reeds_shepp_reaches_the_target_and_respects_bounds():
         assert back == pytest.approx(total, abs=1e-9) and mirrored == pytest.approx(total, abs=1e-9)
 
 
+def test_reeds_shepp_is_a_metric_on_a_grid_of_poses():
+    """Optimality, checked by brute force over intermediate poses: a shortest-curve length obeys the triangle inequality
+    L(a, c) <= L(a, b) + L(b, c) for EVERY b - a word family missing from the candidates shows up as a pose pair whose
+    curve is longer than some two-leg detour (the legs use other families).  Grid of pose pairs around the origin, all
+    grid poses as intermediate points; plus the exact zero on the diagonal and symmetry."""
+    rho = 1.0
+    xs = (-3.0, -1.5, -0.5, 0.0, 0.75, 2.0, 3.5)
+    ths = tuple(k * math.pi / 6 for k in range(12))
+    poses = [(x, y, th) for x in xs for y in xs for th in ths]
+    a = (0.0, 0.0, 0.0)                                  # (the length only depends on the relative pose)
+    la = np.array([front_end.reeds_shepp(a, p, rho)[0] for p in poses])
+    worst = 0.0
+    for i, c in enumerate(poses):
+        lbc = np.array([front_end.reeds_shepp(b, c, rho)[0] for b in poses])
+        slack = la + lbc - la[i]                          # >= 0 for every intermediate pose b
+        worst = min(worst, float(slack.min()))
+        assert slack.min() > -1e-9, (c, poses[int(slack.argmin())], float(slack.min()))
+        assert lbc[i] == pytest.approx(0.0, abs=1e-9)
+    assert worst > -1e-9
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def _rect_centre(p):
     c2r = (VEH.LF + VEH.LB) / 2 - VEH.LB

@@ -766,13 +766,15 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
     return false;
   }
   // replay: the coordinates are the same sums as in the reference's walk
+  // (a loop per side, as long as that side's step count: one loop over all GROW_LIMIT steps with four tests and selects per step
+  //  was 23 k cycles per SQP iteration for 4 x 101 additions)
   BoxD box{xc, yc, xc, yc};
-  for (int n = 1; n <= GROW_LIMIT; ++n) {
-    if (n <= st0) box.y_max += ds;
-    if (n <= st1) box.x_min -= ds;
-    if (n <= st2) box.y_min -= ds;
-    if (n <= st3) box.x_max += ds;
-  }
+  const int lim0 = st0 < GROW_LIMIT ? st0 : GROW_LIMIT, lim1 = st1 < GROW_LIMIT ? st1 : GROW_LIMIT,
+            lim2 = st2 < GROW_LIMIT ? st2 : GROW_LIMIT, lim3 = st3 < GROW_LIMIT ? st3 : GROW_LIMIT;
+  for (int n = 0; n < lim0; ++n) box.y_max += ds;
+  for (int n = 0; n < lim1; ++n) box.x_min -= ds;
+  for (int n = 0; n < lim2; ++n) box.y_min -= ds;
+  for (int n = 0; n < lim3; ++n) box.x_max += ds;
   res = box;
   return (st0 + st1 + st2 + st3) > 0;
 }

@@ -971,8 +971,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CD(C_E + i, t) = Ei;
           S.lo[i] = Ei * S.lo[i];
           S.hi[i] = Ei * S.hi[i];
-          if (S.lo[i] < -OSQP_INFTY * MIN_SCALING && S.hi[i] > OSQP_INFTY * MIN_SCALING) loose |= 1u << i;
-          else if (S.hi[i] - S.lo[i] < RHO_TOL) eq |= 1u << i;
+          // (without branches: as `if (..) loose |= bit; else if (..) eq |= bit;` the two masks became a two-element array in
+          //  scratch, indexed by the outcome, read-modified-written once per row behind a full wait)
+          const bool is_loose = S.lo[i] < -OSQP_INFTY * MIN_SCALING && S.hi[i] > OSQP_INFTY * MIN_SCALING;
+          const bool is_eq = !is_loose && (S.hi[i] - S.lo[i] < RHO_TOL);
+          loose |= is_loose ? (1u << i) : 0u;
+          eq |= is_eq ? (1u << i) : 0u;
         }
       });
       eq &= S.act;

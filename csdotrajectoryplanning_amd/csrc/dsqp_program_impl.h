@@ -851,7 +851,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // are applied to the rows' own-column coefficients and folded into E (the column factors follow below, when the
         // column maxima are complete): only the four kinematic rows' factors outlive their group.
         CSDO_FOR(grp, NROW / 4, {
-          double ln[4], e4[4];
+          double ln[4], e4[4], eacc[4];
+          CSDO_FOR(q, 4, { eacc[q] = SU(14 + 4 * grp + q, t); });   // (in flight while the group's factors are computed)
           CSDO_FOR(q, 4, {
             constexpr int i = 4 * grp + q;
             double rn = 0.0;
@@ -874,7 +875,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             CSDO_FOR(s, 3, {
               if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * e4[q];
             });
-            SU(14 + i, t) = csdo_one_if(pass == 0, SU(14 + i, t)) * e4[q];
+            SU(14 + i, t) = csdo_one_if(pass == 0, eacc[q]) * e4[q];
           });
         });
         CSDO_FOR(k, 3, {   // the timestep's inter-vehicle rows; cleared for the next pass

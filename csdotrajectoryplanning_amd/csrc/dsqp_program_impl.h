@@ -1141,7 +1141,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // between these two barriers: three lanes per row of the inverse, each with two of the row's six accumulation chains
       // (entry j of a row belongs to chain j mod 6, as in the one-lane-per-row form below: same operations in the same order,
       // same bits), joined by two shuffles.  One lane per row was 36 LDS round trips and FMAs deep: 1.5 k cycles of every iteration.
-      if constexpr (ROLE == ROLE_ROW) {
+      // (Not in the 1024-thread class, residency mode 3: with 128 registers per lane the extra code costs its row waves more
+      //  than the product takes on the solver wave - room50's long-horizon agents: 91.9 -> 88.0 ms.)
+      if constexpr (ROLE == ROLE_ROW && MODE != 3) {
         const int x = (int)threadIdx.x, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
         if (x < 128) {
           double a0 = 0.0, a1 = 0.0;
@@ -1167,7 +1169,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           }
         }
       }
-      if constexpr (ROLE == ROLE_BOTH)
+      if constexpr (ROLE == ROLE_BOTH || MODE == 3)
 #endif
       CSDO_TLANES_TOP(t) {
         {

@@ -80,6 +80,7 @@ def lib():
         L.csdo_paths_free.argtypes = [C.POINTER(abi.Paths)]
         L.csdo_paths_free.restype = None
         L.csdo_reeds_shepp.argtypes = [C.c_double * 3, C.c_double * 3, C.c_double, C.c_int32 * 5, C.c_double * 5]
+        L.csdo_front_end_gate_draws.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]
         L.csdo_reeds_shepp.restype = C.c_double
         _LIB = L
     return _LIB

@@ -61,6 +61,13 @@ def plan(starts, goals, dimx, dimy, obstacles, veh, parm=None):
         lib().csdo_paths_free(C.byref(out))
 
 
+def gate_draws(seed, n, glibc=True):
+    """First n draws of the analytic shot's gate generator (csdo_front_end_gate_draws); glibc=True: rand() after srand(seed)."""
+    out = (C.c_uint32 * int(n))()
+    check(lib().csdo_front_end_gate_draws(int(seed), 1 if glibc else 0, int(n), out), "csdo_front_end_gate_draws")
+    return list(out)
+
+
 def reeds_shepp(p0, p1, rho):
     """Shortest Reeds-Shepp curve p0 -> p1.  Returns (length, types[5], lengths[5]); lengths in units of rho, signed."""
     ty = (C.c_int32 * 5)()

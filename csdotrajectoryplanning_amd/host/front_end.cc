@@ -129,6 +129,45 @@ struct PlannedPath {
 // ---------------------------------------------------------------------------------------------------------------------
 // low level: one agent, given the paths of the agents it must yield to
 // ---------------------------------------------------------------------------------------------------------------------
+// The analytic-shot gate's random numbers (environment.h:163: rand() % 10 + 1 after csdo.cc:93's srand(0)).  Owned by the call,
+// so that the entry is re-entrant.  Two sources: a 64-bit LCG (Knuth's MMIX constants, high bits; the default, what the stored
+// paths of tests/golden/front_end_paths were planned with), or - csdo_front_end_parm::rand_glibc - glibc's rand() itself:
+// random_r's TYPE_3 additive feedback generator r[i] = r[i-3] + r[i-31] (mod 2^32), output r[i] >> 1, seeded as srandom_r does
+// (seed 0 is taken as 1; r[i] = 16807 r[i-1] mod 2^31-1 for i < 31; the first 310 outputs discarded): the reference's sequence.
+struct Rng {
+  bool glibc = false;
+  uint64_t lcg = 0;
+  uint32_t r[34] = {0};
+  int k = 0;                      // next position in the glibc generator's ring of 34
+  void seed(uint32_t seed_, bool glibc_) {
+    glibc = glibc_;
+    lcg = seed_;
+    if (!glibc) return;
+    int32_t word = seed_ == 0 ? 1 : (int32_t)seed_;
+    r[0] = (uint32_t)word;
+    for (int i = 1; i < 31; ++i) {
+      const long hi = word / 127773, lo = word % 127773;      // Schrage: 16807 * word mod (2^31 - 1) without overflow
+      word = (int32_t)(16807 * lo - 2836 * hi);
+      if (word < 0) word += 2147483647;
+      r[i] = (uint32_t)word;
+    }
+    for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
+    k = 0;
+    for (int i = 0; i < 310; ++i) (void)step();
+  }
+  uint32_t step() {               // position 34 + n of the sequence, kept in a ring of 34
+    const uint32_t v = r[(k + 34 - 31) % 34] + r[(k + 34 - 3) % 34];
+    r[k % 34] = v;
+    k = (k + 1) % 34;
+    return v >> 1;
+  }
+  uint32_t next() {
+    if (glibc) return step();
+    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(lcg >> 33);
+  }
+};
+
 class LowLevel {
  public:
   LowLevel(const Consts& c, double maxx, double maxy, const std::vector<double>& obstacles, const std::vector<Pose>& goals,
@@ -158,14 +197,10 @@ class LowLevel {
   }
 
   long expanded = 0;
-  uint64_t* rng_state = nullptr;   // one generator per csdo_front_end_plan call, shared by its low-level searches
+  struct Rng* rng_state = nullptr;   // one generator per csdo_front_end_plan call, shared by its low-level searches
 
  private:
-  uint32_t next_random() {          // 64-bit LCG (Knuth's MMIX constants), high bits
-    uint64_t& s = *rng_state;
-    s = s * 6364136223846793005ull + 1442695040888963407ull;
-    return (uint32_t)(s >> 33);
-  }
+  uint32_t next_random() { return rng_state->next(); }
   struct Node {
     Pose s;
     int action;
@@ -451,7 +486,7 @@ class Pbs {
       engines_.back()->rng_state = &rng_;
     }
   }
-  void seed(uint64_t s) { rng_ = s; }
+  void seed(uint32_t s, bool glibc) { rng_.seed(s, glibc); }
   ~Pbs() {
     for (HlNode* n : all_) delete n;
     for (LowLevel* e : engines_) delete e;
@@ -654,7 +689,7 @@ class Pbs {
   std::vector<HlNode*> stack_, all_;
   HlNode* goal_ = nullptr;
   clk::time_point deadline_;
-  uint64_t rng_ = 0;
+  Rng rng_;
 };
 
 }  // namespace
@@ -672,7 +707,7 @@ int front_end_plan(const double* starts, const double* goals, int Na, double dim
   }
   const auto t0 = clk::now();
   Pbs pbs(C, dimx, dimy, obs, S, G);
-  pbs.seed(parm->rand_seed);     // csdo.cc:93 seeds the C library's generator with 0 before the search
+  pbs.seed(parm->rand_seed, parm->rand_glibc != 0);   // csdo.cc:93 seeds the C library's generator with 0 before the search
   const bool ok = pbs.solve(parm->time_limit_s > 0 ? parm->time_limit_s : 20.0, parm->node_limit > 0 ? parm->node_limit : 1000000);
   out->seconds = std::chrono::duration<double>(clk::now() - t0).count();
   out->hl_expanded = (int32_t)pbs.hl_expanded;
@@ -731,7 +766,15 @@ void csdo_front_end_parm_default(csdo_front_end_parm* p) {   // config.yaml of t
   p->node_limit = 0;
   p->rand_seed = 0;
   p->keep_off_lower_goals = 1;
-  p->_reserved = 0;
+  p->rand_glibc = 0;
+}
+
+int csdo_front_end_gate_draws(uint32_t rand_seed, int32_t rand_glibc, int32_t n, uint32_t* out) {
+  if (n < 0 || (n > 0 && !out)) return CSDO_EINVAL;
+  csdo::Rng g;
+  g.seed(rand_seed, rand_glibc != 0);
+  for (int i = 0; i < n; ++i) out[i] = g.next();
+  return CSDO_OK;
 }
 int csdo_front_end_plan(const double* starts, const double* goals, int32_t Na, double dimx, double dimy,
                         const double* obstacles, int32_t n_obs, const csdo_vehicle* veh, const csdo_front_end_parm* parm,

@@ -227,7 +227,9 @@ typedef struct csdo_front_end_parm {
    * rule set.  The default solves 58 / 49 of the 60 / 60 map100 / map50 obstacle instances; profiles/r03_front_end_rules.json
    * holds the counts for both settings. */
   int32_t keep_off_lower_goals;
-  int32_t _reserved;
+  /* 1: the gate of the analytic shot draws from glibc's rand() sequence after srand(rand_seed) (environment.h:163, csdo.cc:93),
+   * reproduced inside the call; 0 (default): from a 64-bit LCG - what the stored benchmark paths were planned with. */
+  int32_t rand_glibc;
 } csdo_front_end_parm;
 typedef struct csdo_paths {
   int32_t Na, status;
@@ -247,6 +249,9 @@ void csdo_paths_free(csdo_paths* p);
  * ReedsSheppStateSpace, an external dependency: environment.h:165-200; this library computes it from the 1990 paper's
  * word families).  types[5]: 0 none, 1 left, 2 straight, 3 right; lengths[5] in units of rho, negative = reverse.
  * Returns the path length (rho * sum |lengths|). */
+/* The first n draws of the generator behind the analytic shot's gate (csdo_front_end_parm::rand_seed, rand_glibc): with
+ * rand_glibc = 1 the values rand() returns after srand(rand_seed) (hybrid_a_star/environment.h:163, csdo.cc:93). */
+int csdo_front_end_gate_draws(uint32_t rand_seed, int32_t rand_glibc, int32_t n, uint32_t* out);
 double csdo_reeds_shepp(const double from[3], const double to[3], double rho, int32_t types[5], double lengths[5]);
 
 /* Independent trajectory validator on the device (the reference checks results the same way after the fact:

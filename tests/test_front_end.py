@@ -82,6 +82,26 @@ def test_reeds_shepp_reaches_the_target_and_respects_bounds():
         assert back == pytest.approx(total, abs=1e-9) and mirrored == pytest.approx(total, abs=1e-9)
 
 
+def test_gate_generator_reproduces_the_c_library_rand_sequence():
+    """csdo.cc:93 seeds the C library's generator with 0 and environment.h:163 draws rand() % 10 + 1 per expansion; with
+    rand_glibc the front end draws the same numbers from a generator of its own (glibc's TYPE_3 algorithm, re-entrant)."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (0, 1, 7, 123456789):
+        libc.srand(seed)
+        want = [libc.rand() for _ in range(2000)]
+        assert front_end.gate_draws(seed, 2000, glibc=True) == want
+    assert front_end.gate_draws(0, 5, glibc=True) == [1804289383, 846930886, 1681692777, 1714636915, 1957747793]
+    assert front_end.gate_draws(0, 5, glibc=False) != front_end.gate_draws(0, 5, glibc=True)
+    # and the search runs with it (the stored benchmark paths were planned with the default generator: no path equality asked)
+    parm = front_end.default_parm()
+    parm.rand_glibc = 1
+    inst = _load("map_100by100_agents10_ex0.yaml")
+    cp = front_end.plan(inst.starts, inst.goals, inst.dimx, inst.dimy, inst.obstacles, VEH, parm=parm)
+    assert cp is not None
+    _check_paths(cp, inst)
+
+
 def test_reeds_shepp_is_a_metric_on_a_grid_of_poses():
     """Optimality, checked by brute force over intermediate poses: a shortest-curve length obeys the triangle inequality
     L(a, c) <= L(a, b) + L(b, c) for EVERY b - a word family missing from the candidates shows up as a pose pair whose

@@ -55,10 +55,12 @@ int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) 
   // threads with 128 registers per lane: correct but spills; horizons that long are outside the benchmark sets)
   // The 256-thread class runs two workgroups per CU, so it only takes agents whose working set fits half the LDS; a
   // short horizon that does not (Nt > ~105 with 25 obstacles) runs in the 512-thread class with half its lanes idle.
-  int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : 1024);
+  // Horizons 257 .. 384 take 768 threads: three waves per SIMD leave 168 registers per lane instead of 128 (measured on the
+  // room set, whose long agents have 257 .. 295 timesteps).
+  int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : (nt <= 384 ? 768 : 1024));
   if (block == 256 && dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) > LDS_CAP_2WG) block = 512;
   *rows_lds = 0;
-  if (block == 1024) {
+  if (block >= 768) {
     *mode = 3;
   } else if (dsqp_lds_bytes(nt, n_obs, n_planes, 0, true) <= (block == 256 ? LDS_CAP_2WG : LDS_CAP)) {   // (256: keep two per CU)
     *mode = 0;
@@ -76,6 +78,7 @@ hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroup
     case 2560: return launch_variant<256, 0, true>(B, g, workgroups, stream);
     case 5120: return launch_variant<512, 0, true>(B, g, workgroups, stream);
     case 5121: return launch_variant<512, 1, true>(B, g, workgroups, stream);
+    case 7683: return launch_variant<768, 3, true>(B, g, workgroups, stream);
     case 10243: return launch_variant<1024, 3, true>(B, g, workgroups, stream);
   }
   return hipErrorInvalidValue;

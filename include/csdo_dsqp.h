@@ -148,10 +148,10 @@ double csdo_dsqp_last_kernel_seconds(csdo_handle h);
  * out[2] H2D copies (+ first-call device allocation), out[3] D2H copies, out[4] scattering into the caller's buffers. */
 int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]);
 /* How the uploaded batch is launched: agents are grouped by kernel class - workgroup size by horizon (256 threads and two
- * workgroups per CU for Nt <= 128 when the working set fits 80 KB, 512 up to Nt = 256, 1024 beyond) and LDS residency by
+ * workgroups per CU for Nt <= 128 when the working set fits 80 KB, 512 up to Nt = 256, 768 up to 384, 1024 beyond) and LDS residency by
  * working set: 0 = exchange vectors, bounds and the third of the factor that is not in registers in LDS (per agent also
  * the inter-vehicle rows' duals / slacks, where they fit); 1 = that part of the factor read from the workspace instead
- * (512-thread class only); 3 = the 1024-thread class: exchange vectors only.  Every group is a set of persistent
+ * (512-thread class only); 3 = the 768- and 1024-thread classes: exchange vectors only.  Every group is a set of persistent
  * workgroups that take its agents off a queue ordered heaviest first, and the groups run concurrently.  `lds_bytes` may
  * be the full 80 / 160 KB of the class: what the agents do not need caches the planes' read-only coefficients.
  * Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
@@ -159,7 +159,7 @@ int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]);
  * agents serially, sqp/dsqp_solver.cc:1198-1205). */
 typedef struct csdo_launch_group {
   int32_t n_agents;
-  int32_t threads;             /* per workgroup: 256, 512 or 1024 */
+  int32_t threads;             /* per workgroup: 256, 512, 768 or 1024 */
   int32_t residency_mode;      /* 0, 1 or 3, see above */
   int32_t max_nt;
   int64_t lds_bytes;
@@ -170,7 +170,7 @@ int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t c
 int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents);
 /* Testing / tuning knob, from the next upload on (0 restores the automatic choice): 1 keeps the inter-vehicle rows' duals
  * and slacks in the workspace for every agent (the mode stays 0); >= 2 additionally puts the 512-thread class into mode 1.
- * The 256- and 1024-thread classes have one mode each.  Results do not depend on it, only the speed does. */
+ * The 256-, 768- and 1024-thread classes have one mode each.  Results do not depend on it, only the speed does. */
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
 /* The launcher's relative work estimate per agent (the quantity the launch order and the CU shares of the groups come
  * from: horizon, plane count and how much of the initial guess sits in tight spots), in upload order; host code, no GPU

@@ -1,5 +1,5 @@
 """Diagnostic: where the CU time of a batch goes, summed over all agents (needs `make -C csdotrajectoryplanning_amd/csrc prof`).
-usage: python scripts/profile_phases_sum.py [instance ids, comma separated] [map100|map50]"""
+usage: python scripts/profile_phases_sum.py [instance ids, comma separated] [map100|map50|room50|agents100]"""
 import ctypes as C
 import os
 import sys
@@ -12,7 +12,11 @@ NAMES = ["other", "corridor", "assemble", "ruiz", "warmstart", "factor", "rhs", 
          "info/check", "bookkeeping", "hot load/save", "fwd barrier", "bwd barrier", "-"]
 ids = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 1, 2, 4]
 wl = sys.argv[2] if len(sys.argv) > 2 else "map100"
-worlds = [(workloads.map100_world(k) if wl == "map100" else workloads.map50_world(k))[0] for k in ids]
+if wl in ("map100", "map50"):
+    worlds = [(workloads.map100_world(k) if wl == "map100" else workloads.map50_world(k))[0] for k in ids]
+else:   # any other workload of workloads.WORKLOADS (room50, agents100, ...): `ids` index its job list
+    jobs = workloads.workload_jobs(wl)
+    worlds = [workloads.build_job(jobs[k])[0] for k in ids]
 h = DsqpHandle(0)
 h.upload(worlds); h.run(); ks = h.run(); sols = h.download()
 Na = sum(w.Na for w in worlds)

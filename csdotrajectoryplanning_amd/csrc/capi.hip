@@ -125,6 +125,20 @@ static int build_groups(csdo_handle h) {
     ad.rows_lds = rows;
     need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode, rows != 0);
   }
+  // One residency mode for the 768-thread class of a batch: with F_r in LDS (mode 2) where every such agent fits, else the
+  // lean mode 3 for all of them.  Every (class, mode) pair is a launch group with streams of its own, HIP maps streams onto four
+  // hardware queues, and kernels that share a queue run one after the other: with a fourth group the room set's batch took
+  // 78 ms instead of 61 (58 with GPU_MAX_HW_QUEUES=8) although each of its groups had become faster.
+  {
+    bool any768_lean = false;
+    for (int a = 0; a < Na; ++a) any768_lean |= key[a].block == 768 && (key[a].mode == 3 || h->min_mode >= 3);
+    if (any768_lean)
+      for (int a = 0; a < Na; ++a)
+        if (key[a].block == 768 && key[a].mode != 3) {
+          key[a].mode = 3;
+          need[a] = dsqp_lds_bytes(hbm.agents[a].Nt, hb.worlds[hbm.agents[a].world].n_obs, hbm.agents[a].n_planes, 3, false);
+        }
+  }
   h->order.resize(Na);
   for (int a = 0; a < Na; ++a) h->order[a] = a;
   std::stable_sort(h->order.begin(), h->order.end(), [&](int p, int q) {
@@ -354,7 +368,7 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
   // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
   {
-    const double mode_cost[4] = {1.0, 1.2, 1.2, 2.5};
+    const double mode_cost[4] = {1.0, 1.2, 3.5, 5.5};   // cycles per ADMM iteration relative to mode 0 (measured: 16 k / 55 k / 87 k)
     std::vector<double> work(h->groups.size(), 0.0);
     double total = 0.0;
     for (size_t g = 0; g < h->groups.size(); ++g) {

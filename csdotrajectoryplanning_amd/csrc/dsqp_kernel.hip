@@ -38,7 +38,7 @@ size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) 
   const int st = (nt + 1) & ~1;
   // exchange vectors vec, pr, rhs, carry (6 each) + bounds of the home rows 22 (the t -> t-1 hand-over aliases them) +
   // the third of the factor that is not in the solver lane's registers 34 (mode 0); mode 3: vec, pr, rhs, carry, carry2
-  const size_t per_lane = mode == 3 ? 30 : (mode == 1 ? 46 : (size_t)LD_block);
+  const size_t per_lane = mode == 3 ? 30 : (mode == 2 ? 60 : (mode == 1 ? 46 : (size_t)LD_block));
   const size_t n_obs_pad = (3 * (size_t)n_obs + 1) & ~(size_t)1, n_pc_pad = (3 * (size_t)n_planes + 1) & ~(size_t)1;
   const size_t planes = (mode == 0 && rows_lds) ? n_pc_pad + (size_t)LD_prow * n_planes : 0;   // rhs shares + duals / slacks
   return (per_lane * st + n_obs_pad + 32 + 2 * TAIL_N + TAIL_N * 38 + planes) * sizeof(double);
@@ -60,8 +60,8 @@ int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) 
   int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : (nt <= 384 ? 768 : 1024));
   if (block == 256 && dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) > LDS_CAP_2WG) block = 512;
   *rows_lds = 0;
-  if (block >= 768) {
-    *mode = 3;
+  if (block >= 768) {   // nothing of the factor in registers: F_r in LDS where that fits (mode 2), else from the workspace
+    *mode = (block == 768 && dsqp_lds_bytes(nt, n_obs, n_planes, 2, false) <= LDS_CAP) ? 2 : 3;
   } else if (dsqp_lds_bytes(nt, n_obs, n_planes, 0, true) <= (block == 256 ? LDS_CAP_2WG : LDS_CAP)) {   // (256: keep two per CU)
     *mode = 0;
     *rows_lds = 1;
@@ -78,6 +78,7 @@ hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroup
     case 2560: return launch_variant<256, 0, true>(B, g, workgroups, stream);
     case 5120: return launch_variant<512, 0, true>(B, g, workgroups, stream);
     case 5121: return launch_variant<512, 1, true>(B, g, workgroups, stream);
+    case 7682: return launch_variant<768, 2, true>(B, g, workgroups, stream);
     case 7683: return launch_variant<768, 3, true>(B, g, workgroups, stream);
     case 10243: return launch_variant<1024, 3, true>(B, g, workgroups, stream);
   }

@@ -39,7 +39,13 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   sh.carry = aligned16(sh.rhs + 6 * st);
   sh.red = sh.vec;
   double* rest = sh.carry + 6 * st;
-  if constexpr (MODE != 3) {
+  if constexpr (MODE == 2) {   // the lean layout plus all of F_r (36 doubles per timestep); carry2 is only used between blocks
+    sh.stash = sh.vec;
+    sh.lohi = nullptr;
+    sh.fx = aligned16(rest);
+    sh.carry2 = sh.fx;
+    rest = sh.fx + 36 * st;
+  } else if constexpr (MODE != 3) {
     sh.stash = sh.vec;
     sh.lohi = aligned16(rest);
     sh.carry2 = sh.lohi;

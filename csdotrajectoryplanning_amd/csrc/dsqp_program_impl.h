@@ -15,7 +15,9 @@ namespace csdo {
 #define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
 // F_r of node t: the solver lane's registers for the first ER_REG entries, LDS for the rest and for the pivot inverse;
 // everything from the workspace for long horizons
-#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t))))
+// (MODE 2: the lean modes' layout - nothing of the factor in registers - with all of F_r in LDS, 36 doubles per timestep)
+#define FX2(k, t) sh.fx[(t) * 36 + (k)]
+#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : (MODE == 2 ? FX2(k, t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t)))))
 #define SINV(k, t) (MODE >= 1 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 // set-up stage scratch, field-major over the ADMM block's exchange arrays (see "assemble the QP")
 #define SU(k, t) sh.vec[(size_t)(k) * (size_t)csdo_opaque_s(sh.stride) + (unsigned)(t)]
@@ -681,7 +683,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   }
   CSDO_SYNC();
 
-  constexpr int n_block_fields = (MODE == 3 ? 30 : (MODE == 1 ? 46 : LD_block));
+  constexpr int n_block_fields = (MODE == 3 ? 30 : (MODE == 2 ? 60 : (MODE == 1 ? 46 : LD_block)));
   // grow_box's per-obstacle step counts (BoxCache): the ADMM block's LDS arrays are idle whenever boxes are grown
 #if defined(CSDO_LANE_MODE_DEVICE)
   // (all but the last two fields of them: those carry the initial boxes' status flags, written while other lanes still grow)
@@ -1143,7 +1145,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // same bits), joined by two shuffles.  One lane per row was 36 LDS round trips and FMAs deep: 1.5 k cycles of every iteration.
       // (Not in the 1024-thread class, residency mode 3: with 128 registers per lane the extra code costs its row waves more
       //  than the product takes on the solver wave - room50's long-horizon agents: 91.9 -> 88.0 ms.)
-      if constexpr (ROLE == ROLE_ROW && MODE != 3) {
+      if constexpr (ROLE == ROLE_ROW && MODE < 2) {
         const int x = (int)threadIdx.x, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
         if (x < 128) {
           double a0 = 0.0, a1 = 0.0;
@@ -1169,7 +1171,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           }
         }
       }
-      if constexpr (ROLE == ROLE_BOTH || MODE == 3)
+      if constexpr (ROLE == ROLE_BOTH || MODE >= 2)
 #endif
       CSDO_TLANES_TOP(t) {
         {
@@ -1663,7 +1665,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // lane and block).  Only the bounds, read once per iteration, are staged into LDS again: the factorisation's exchange
         // columns and the residual update's hand-over overwrite them (layout: Shm::lohi).
         LaneState& S = CSDO_LS(t);
-        if constexpr (MODE != 3) {
+        if constexpr (MODE < 2) {
           CSDO_FOR(i, 13, { SH(lohi, i, t) = WS(W_LO + i, t); });
           CSDO_FOR(i, 9, { SH(lohi, 13 + i, t) = WS(W_HI + 7 + i, t); });
         }
@@ -1672,7 +1674,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_SLANES(t) {  // load the solver-lane cache: 60 doubles of the node's factor in registers, 33 in LDS
         SolvRegs& V = CSDO_SS(t);
         CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
-        if constexpr (MODE != 3) {
+        if constexpr (MODE == 2) CSDO_FOR(k, 36, { FX2(k, t) = FE(36 + k, t); });
+        if constexpr (MODE < 2) {
           CSDO_FOR(k, ER_REG, { V.er[k] = FE(36 + k, t); });
           if constexpr (MODE == 0) {
             CSDO_FOR(k, FX_ER, { SH(fx, k, t) = FE(36 + ER_REG + k, t); });
@@ -1756,7 +1759,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           // mode 3: the 22 bounds of the home rows come from the workspace; one batch of loads in front of everything
           // else of the update (a load per row inside the loop below costs an L2 round trip each)
           double bnd[22];
-          if constexpr (MODE == 3) {
+          if constexpr (MODE >= 2) {
             CSDO_FOR(k, 13, { bnd[k] = WS(W_LO + k, t); });
             CSDO_FOR(k, 6, { bnd[13 + k] = WS(W_HI + 7 + k, t); });
             CSDO_FOR(k, 3, { bnd[19 + k] = WS(W_HI + 13 + k, t); });
@@ -1787,13 +1790,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
               double lo_i, hi_i;
               // bounds in the packed order of Shm::lohi: from LDS, or (mode 3) from the batch fetched above
-              if constexpr (i < 7) lo_i = hi_i = (MODE == 3) ? bnd[i] : SH(lohi, i, t);
+              if constexpr (i < 7) lo_i = hi_i = (MODE >= 2) ? bnd[i] : SH(lohi, i, t);
               if constexpr (i >= 7 && i < 13) {
-                lo_i = (MODE == 3) ? bnd[i] : SH(lohi, i, t);
-                hi_i = (MODE == 3) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                lo_i = (MODE >= 2) ? bnd[i] : SH(lohi, i, t);
+                hi_i = (MODE >= 2) ? bnd[i + 6] : SH(lohi, i + 6, t);
               }
               if constexpr (i >= 13) {
-                hi_i = (MODE == 3) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                hi_i = (MODE >= 2) ? bnd[i + 6] : SH(lohi, i + 6, t);
                 lo_i = -hi_i;
               }
               const double zn = hot_min(hot_max(zr + rinv * S.y[i], lo_i), hi_i);

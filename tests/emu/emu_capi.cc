@@ -13,11 +13,11 @@
 
 using namespace csdo;
 
-// mode: residency of the ADMM blocks' state (agent_program in dsqp_program.h): 0 (10: with the rows' state in LDS), 1, 3; all give identical results
+// mode: residency of the ADMM blocks' state (agent_program in dsqp_program.h): 0 (10: with the rows' state in LDS), 1, 2, 3; all give identical results
 // n_threads > 1: agents are solved concurrently (each has its own workspace slice and its own "LDS"), results unchanged
 extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode,
                                        int n_threads) {
-  if (mode != 0 && mode != 1 && mode != 3 && mode != 10) return CSDO_EINVAL;   // 10: mode 0 with the rows' state in "LDS"
+  if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 10) return CSDO_EINVAL;   // 10: mode 0 with the rows' state in "LDS"
   const bool rows_lds = mode == 10;
   if (rows_lds) mode = 0;
   HostBatch hb;
@@ -66,7 +66,12 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     sh.carry = sh.rhs + 6 * st;
     sh.red = sh.vec;
     double* rest = sh.carry + 6 * st;
-    if (mode != 3) {
+    if (mode == 2) {
+      sh.stash = sh.vec;
+      sh.fx = rest;
+      sh.carry2 = sh.fx;
+      rest = sh.fx + 36 * st;
+    } else if (mode != 3) {
       sh.stash = sh.vec;
       sh.lohi = rest;
       sh.carry2 = sh.lohi;
@@ -99,6 +104,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     ProgramOut po{};
     if (mode == 0) agent_program<ROLE_BOTH, 0>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 1) agent_program<ROLE_BOTH, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else if (mode == 2) agent_program<ROLE_BOTH, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else agent_program<ROLE_BOTH, 3>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     sqp[a] = po.sqp_iters;
     admm[a] = po.admm_iters;

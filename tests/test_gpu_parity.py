@@ -140,15 +140,16 @@ def test_gpu_edge_cases(gpu_handle, oracle, veh_parm):
     _check(oracle.solve(w2, 1), gpu_handle.solve(w2))                    # shortest horizon Nt = 2
 
 
-@pytest.mark.parametrize("L,Nt,threads", [(100, 301, 768), (140, 421, 1024)])
-def test_gpu_long_horizons_use_the_wide_kernels(gpu_handle, oracle, veh_parm, L, Nt, threads):
-    """Horizons beyond 256 timesteps: 768 threads (168 registers per lane) up to 384, 1024 threads (128) up to 512."""
+@pytest.mark.parametrize("L,Nt,threads,mode", [(90, 271, 768, 2), (120, 361, 768, 3), (140, 421, 1024, 3)])
+def test_gpu_long_horizons_use_the_wide_kernels(gpu_handle, oracle, veh_parm, L, Nt, threads, mode):
+    """Horizons beyond 256 timesteps: 768 threads (168 registers per lane) up to 384 - with F_r in LDS (mode 2) while that
+    fits, about 296 timesteps -, 1024 threads (128 registers) up to 512."""
     veh, parm = veh_parm
     w = helpers.straight_line_world(veh, parm, Na=1, L=L, dim=600.0)
     assert w.Nt == Nt
     _check(oracle.solve(w, 1), gpu_handle.solve(w))
     gpu_handle.upload([w])
-    assert [g["threads"] for g in gpu_handle.launch_groups()] == [threads]
+    assert [(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()] == [(threads, mode)]
 
 
 def test_gpu_fixed_corridor_mode_is_tight(gpu_handle, oracle, veh_parm):

@@ -60,7 +60,7 @@ def test_lds_residency_modes_are_bit_identical(emu, veh_parm):
     veh, parm = veh_parm
     world, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     ref = emu.solve(world, 0)
-    for mode in (10, 1, 3):   # 10: mode 0 with the inter-vehicle rows' state in LDS
+    for mode in (10, 1, 2, 3):   # 10: mode 0 with the inter-vehicle rows' state in LDS; 2: the lean layout with F_r in LDS
         got = emu.solve(world, mode)
         assert np.array_equal(ref.solutions, got.solutions) and np.array_equal(ref.corridors, got.corridors)
         assert np.array_equal(ref.admm_iters, got.admm_iters) and np.array_equal(ref.last_status, got.last_status)

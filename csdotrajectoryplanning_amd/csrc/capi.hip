@@ -80,7 +80,6 @@ struct csdo_handle_s {
   std::vector<int32_t> order;
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> g_begin, g_end, g_zeroed, g_end2;
-  std::vector<hipStream_t> side2;   // streams of the groups' second (elastic) launches
   HostBatch hb;
   bool uploaded = false;
   int n_worlds = 0;
@@ -176,22 +175,26 @@ static int build_groups(csdo_handle h) {
     if (any && g.mode == 0 && g.lds_bytes <= dsqp_lds_capacity())
       g.lds_bytes = dsqp_workgroups_per_cu(g.block, g.lds_bytes) == 2 ? dsqp_lds_capacity_two_per_cu() : dsqp_lds_capacity();
   }
-  while (h->side.size() + 1 < h->groups.size()) {
+  // Streams.  HIP maps streams onto four hardware queues (GPU_MAX_HW_QUEUES), round robin in the order of their creation, and
+  // kernels that share a queue run one after the other: with three launch groups and a stream per launch - six - a group's
+  // FIRST launch was seen to wait tens of milliseconds behind another group's kernel (room set: 77 ms instead of 61 with
+  // every group faster than before).  So the handle owns four streams, created back to back, and rations them: a stream per
+  // group's first launch (groups beyond the fourth queue up behind the first ones), the streams that are left for the second
+  // ("elastic") launches - one each with two groups, one for all with three, none beyond.
+  while (h->side.size() < 3) {
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CSDO_EDEVICE;
     h->side.push_back(s);
   }
   while (h->g_begin.size() < h->groups.size()) {
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    hipStream_t s2 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess ||
-        hipEventCreate(&e3) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess)
+        hipEventCreate(&e3) != hipSuccess)
       return CSDO_EDEVICE;
     h->g_begin.push_back(e0);
     h->g_end.push_back(e1);
     h->g_zeroed.push_back(e2);
     h->g_end2.push_back(e3);
-    h->side2.push_back(s2);
   }
   return CSDO_OK;
 }
@@ -251,7 +254,6 @@ void csdo_dsqp_destroy(csdo_handle h) {
   for (hipEvent_t e : h->g_end) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_zeroed) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_end2) (void)hipEventDestroy(e);
-  for (hipStream_t s : h->side2) (void)hipStreamDestroy(s);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -445,8 +447,9 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   RUN_OK(hipEventRecord(h->ev0, s));
   const int ng = (int)h->groups.size();
+  auto primary_stream = [&](int g) { return (g & 3) == 0 ? s : h->side[(g & 3) - 1]; };
   for (int g = 0; g < ng; ++g) {   // fork: every group starts when the caller's stream reaches this point
-    hipStream_t gs = g == 0 ? s : h->side[g - 1];
+    hipStream_t gs = primary_stream(g);
     if (g > 0) RUN_OK(hipStreamWaitEvent(gs, h->ev0, 0));
     RUN_OK(hipEventRecord(h->g_begin[g], gs));
     RUN_OK(hipMemsetAsync(h->groups[g].queue, 0, sizeof(int), gs));
@@ -456,12 +459,15 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   }
   // second launches: same queues, workgroups that start on CUs other groups release; the first group's comes last so
   // that it does not take CUs ahead of the later groups' first launches
+  std::vector<char> second(ng, 0);
   for (int g = ng - 1; g >= 0; --g) {
-    if (h->groups[g].elastic <= 0) continue;
-    RUN_OK(hipStreamWaitEvent(h->side2[g], h->g_zeroed[g], 0));
-    RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, h->side2[g]));
-    RUN_OK(hipEventRecord(h->g_end2[g], h->side2[g]));
+    if (h->groups[g].elastic <= 0 || ng > 3) continue;
+    hipStream_t es = ng == 1 ? h->side[0] : (ng == 2 ? h->side[1 + g] : h->side[2]);   // (what the first launches leave)
+    RUN_OK(hipStreamWaitEvent(es, h->g_zeroed[g], 0));
+    RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, es));
+    RUN_OK(hipEventRecord(h->g_end2[g], es));
     RUN_OK(hipStreamWaitEvent(s, h->g_end2[g], 0));
+    second[g] = 1;
   }
   for (int g = 1; g < ng; ++g) RUN_OK(hipStreamWaitEvent(s, h->g_end[g], 0));   // join
   RUN_OK(hipEventRecord(h->ev1, s));
@@ -470,7 +476,7 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   for (int g = 0; g < ng; ++g) {
     RUN_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end[g]));
     h->groups[g].seconds = (double)ms * 1e-3;
-    if (h->groups[g].elastic > 0) {   // the group is done when both of its launches are
+    if (second[g]) {   // the group is done when both of its launches are
       RUN_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end2[g]));
       h->groups[g].seconds = std::max(h->groups[g].seconds, (double)ms * 1e-3);
     }

@@ -171,7 +171,8 @@ int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t c
 int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents);
 /* Testing / tuning knob, from the next upload on (0 restores the automatic choice): 1 keeps the inter-vehicle rows' duals
  * and slacks in the workspace for every agent (the mode stays 0); >= 2 additionally puts the 512-thread class into mode 1.
- * The 256-, 768- and 1024-thread classes have one mode each.  Results do not depend on it, only the speed does. */
+ * >= 3 additionally keeps the 768-thread class in mode 3.  The 256- and 1024-thread classes have one mode each.  Results do
+ * not depend on it, only the speed does. */
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
 /* The launcher's relative work estimate per agent (the quantity the launch order and the CU shares of the groups come
  * from: horizon, plane count and how much of the initial guess sits in tight spots), in upload order; host code, no GPU

@@ -107,6 +107,25 @@ def test_gpu_lds_residency_modes_are_bit_identical(gpu_handle, veh_parm):
         gpu_handle.set_min_residency_mode(0)
 
 
+def test_gpu_wide_class_residency_modes_are_bit_identical(gpu_handle, veh_parm):
+    """The 768-thread class with all of F_r in LDS (mode 2) and without (mode 3, knob 3): the same doubles, read from elsewhere.
+    Two lanes 3.5 m apart, so that the inter-vehicle rows take part."""
+    veh, parm = veh_parm
+    w = helpers.straight_line_world(veh, parm, Na=2, L=90, dim=600.0, spacing=3.5)
+    assert w.Nt == 271 and w.plane_off[-1] > 0
+    ref = gpu_handle.solve_batch([w])
+    assert [(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()] == [(768, 2)]
+    try:
+        gpu_handle.set_min_residency_mode(3)
+        got = gpu_handle.solve_batch([w])
+        assert [(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()] == [(768, 3)]
+        for r, g in zip(ref, got):
+            assert np.array_equal(r.solutions, g.solutions) and np.array_equal(r.corridors, g.corridors)
+            assert np.array_equal(r.admm_iters, g.admm_iters) and np.array_equal(r.last_status, g.last_status)
+    finally:
+        gpu_handle.set_min_residency_mode(0)
+
+
 def test_gpu_batch_equals_separate_solves(gpu_handle, veh_parm):
     veh, parm = veh_parm
     w1, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)

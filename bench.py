@@ -15,11 +15,11 @@ Either way the agents of the job are SHARDED by sharding.shard_batch_plan: rank 
 concatenated agents (the reference's loop over agents is what shards, sqp/dsqp_solver.cc:1198-1220), builds only the worlds
 its block overlaps, solves its block, and the step ends with the path's only collective, the all-gather of the final
 trajectories on the device pointer.
---scaling weak        (default) the job is N copies of the workload (the stand-in worlds of copy c seeded with 60 c): the
-                      per-GPU work is fixed as N grows
---scaling strong      the job is ONE copy of the workload whatever N - BASELINE configs[3] / [4] read literally: one workload
-                      at 1 / 2 / 4 / 8 GPUs.  Its floor is the workload's longest agent (map100: ~40 ms of a ~80 ms step), so
-                      the expected curve is 80 -> ~47 -> ~42 -> ~40 ms, not 1/N
+--scaling strong      (default) the job is ONE copy of the workload whatever N - BASELINE's metric read literally: one workload
+                      at 1 / 2 / 4 / 8 GPUs.  Its floor is the workload's longest agent (map100: ~35 ms of a ~65 ms step), so
+                      the expected curve flattens at that floor, not 1/N; the line also carries `strong_scaling_floor_ms`
+--scaling weak        the job is N copies of the workload (the stand-in worlds of copy c seeded with 60 c): the per-GPU
+                      work is fixed as N grows
 Blocks are balanced by the launcher's own per-agent work estimate (csdo_dsqp_estimate_work), not by agent count.
 --force-dist          N = 1 with a one-rank "nccl" group: RCCL initialisation, the all-gather on the solver's device buffer
                       and the stream ordering run on the one GPU there is
@@ -125,8 +125,9 @@ def main():
     ap.add_argument("--front", choices=("auto", "stand-in"), default="auto",
                     help="initial guesses: the front end's stored paths where it solves the instance (auto, default) or the "
                          "seeded stand-in for every instance (the round-1 workload, for like-for-like comparisons)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: the sharded job is N copies of the workload (weak, default) or one copy (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: the sharded job is one copy of the workload whatever N (strong, default: BASELINE's metric is "
+                         "ONE workload at 1/2/4/8 GPUs) or N copies of it (weak)")
     ap.add_argument("--instances", type=int, default=None, help="instances of the set (default: the whole set)")
     ap.add_argument("--setup-procs", type=int, default=32, help="processes building the worlds (1: in-process, no fork; "
                                                                   "use that under rocprofv3)")
@@ -142,7 +143,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    strong = world_size > 1 and args.scaling == "strong"
+    strong = args.scaling == "strong"
     copies = 1 if (strong or world_size == 1) else world_size
     sharded = world_size > 1 or args.force_dist
 
@@ -239,10 +240,14 @@ def main():
         h.upload([full0])                      # device buffers exist now: this is the steady-state upload
         t_upload1 = time.perf_counter() - t_u0
         h.run(stream)
-        single_kernel = min(h.run(stream) for _ in range(3))
-        t_d0 = time.perf_counter()
-        sol0 = h.download()[0]
-        t_download1 = time.perf_counter() - t_d0
+        single_kernel, t_download1, sol0 = None, None, None
+        for _ in range(3):                     # best of 3; everything reported about the run comes from that one run
+            ks = h.run(stream)
+            t_d0 = time.perf_counter()
+            s0 = h.download()[0]
+            t_dl = time.perf_counter() - t_d0
+            if single_kernel is None or ks < single_kernel:
+                single_kernel, t_download1, sol0 = ks, t_dl, s0
         single = {
             "workload": "%s alone: Na=%d, Nt=%d, %d planes" % (infos[0]["instance"], full0.Na, full0.Nt,
                                                                int(full0.plane_off[-1])),
@@ -442,6 +447,52 @@ def main():
         flops_step = float((it_f * (718.0 * Nt_agent + 88.0 * K_agent + 2592.0)).sum())
         lds_bytes_step = float((it_f * 8.0 * (139.0 * Nt_agent + 42.0 * K_agent + 1440.0)).sum())
         FP64_PEAK_TF, LDS_PEAK_TBS = 78.6, 157.0
+        # ---- the roofline object.  The contract's figure (algorithmic bytes per agent-iteration over the kernel's
+        # duration against 8 TB/s) prices every iteration as if factor, rows and iterate streamed from HBM; the design keeps them
+        # in registers and LDS, so that figure is NOMINAL and passes 1.0 as the kernel gets faster: it is reported under
+        # `nominal_hbm`, flagged when it does.  `bound` / `achieved` / `peak` / `frac` describe the resource that is closest to its
+        # own ceiling among those the kernel really uses - every one of them a fraction that cannot pass 1:
+        #   valu_issue  SQ_INSTS_VALU x 4 cycles per SIMD-seconds available (PMC; every vector instruction priced as one 4-cycle
+        #               issue slot of a lone wave; 1024 SIMDs x 2.4 GHz)            [from the newest matching profiles/ summary]
+        #   hbm         counter bytes (2 x FETCH_SIZE + WRITE_SIZE) / time against 8 TB/s                             [PMC]
+        #   fp64        F_iter flops of the executed iterations / time against 78.6 TFLOP/s                          [model]
+        #   lds         L_iter bytes / time against 157 TB/s                                                         [model]
+        fp64_ach = flops_step / kernel_avg / 1e12
+        lds_ach = lds_bytes_step / kernel_avg / 1e12
+        SIMD_CYCLES_PEAK = 1024 * 2.4e9
+        resources = {
+            "fp64": {"achieved": fp64_ach, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": fp64_ach / FP64_PEAK_TF,
+                     "source": "model: 718 Nt + 88 K + 2592 flop per agent-iteration (ADMM iterations only)"},
+            "lds": {"achieved": lds_ach, "peak": LDS_PEAK_TBS, "unit": "TB/s", "frac": lds_ach / LDS_PEAK_TBS,
+                    "source": "model: 8 (139 Nt + 42 K + 1440) bytes per agent-iteration (ADMM iterations only)"},
+        }
+        if hbm_frac is not None and traffic is not None:
+            resources["hbm"] = {"achieved": hbm_frac * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                                "source": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, %s" % pmc_src}
+        if valu_frac is not None:
+            resources["valu_issue"] = {"achieved": valu_frac * SIMD_CYCLES_PEAK / 1e9, "peak": SIMD_CYCLES_PEAK / 1e9,
+                                       "unit": "G SIMD-cycles/s", "frac": valu_frac,
+                                       "source": "rocprofv3 SQ_INSTS_VALU x 4 cycles, %s" % pmc_src}
+        bound = max(resources, key=lambda k: resources[k]["frac"])
+        nominal = achieved / HBM_PEAK_GBS
+        roofline = {"bound": bound, "achieved": resources[bound]["achieved"], "peak": resources[bound]["peak"],
+                    "unit": resources[bound]["unit"], "frac": resources[bound]["frac"], "traffic": traffic,
+                    "binding": "dependency latency of one workgroup per agent (cross-lane exchange + barriers + dependent fp64 "
+                               "chains): no throughput resource is near its ceiling; `bound` names the one that is closest "
+                               "(highest measured fraction), `resources` lists all of them",
+                    "resources": resources,
+                    "nominal_hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nominal,
+                                    "exceeds_peak": bool(nominal > 1.0),
+                                    "note": "SURVEY 8(d)'s contract figure: W_iter = 2280 Nt + 416 K_a algorithmic bytes per "
+                                            "agent-iteration of the dominant kernel's launch / its average duration against 8 TB/s; "
+                                            "nominal - the working set is on-chip, so it is not a ceiling and can pass 1"},
+                    "hbm_counter_frac": hbm_frac, "valu_fp64_issue_frac": valu_frac, "pmc_source": pmc_src,
+                    "kernel": "dsqp_agent_kernel<%d, %d, true>" % (dom["threads"], dom["residency_mode"]),
+                    "kernel_avg_ms": dom_avg * 1e3, "algorithmic_bytes_per_launch": gbytes[gd],
+                    "all_kernels": {"algorithmic_bytes_per_step": float(bytes_agent.sum()), "avg_ms": kernel_avg * 1e3,
+                                    "achieved": float(bytes_agent.sum()) / kernel_avg / 1e9}}
+        # floor of the strong-scaling curve: the job's longest agent (device time of the last step)
+        floor_ms = max(float(s_.t_max_individual) for s_ in sols) * 1e3
         Nts = sorted(w.Nt for w in worlds)
         n_agents = int(sum(w.Na for w in worlds))
         wl_names = {"map100": "map100by100/agents50/obstacle set", "map50": "map50by50/agents25/obstacle set",
@@ -458,11 +509,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if (world_size == 1 or not strong) else "strong",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
+            "strong_scaling_floor_ms": floor_ms,
             "data": "the reference's benchmark instance files (tests/golden/instances = benchmark/map100by100, map50by50, room of "
-                    "the reference); coarse paths from this repository's own front end, stored; no synthetic maps",
+                    "the reference), no synthetic maps; coarse paths: %d of %d worlds from this repository's own front end "
+                    "(stored), %d from the seeded stand-in generator (instances the search does not solve)"
+                    % (n_front, len(infos), len(infos) - n_front),
             "value_e2e": (e2e["agent_qp_iterations_per_sec"] if e2e else None),
             "value_is": "kernels only, inputs resident in HBM (the contract's `value`); value_e2e = the same iterations over the "
                         "PCIe-inclusive DO phase (do_phase_e2e.total_ms)",
@@ -497,25 +551,7 @@ def main():
             "validation": validation,
             "batch_ms": {"load_paths_and_bridge_host": t_pre * 1e3, "solve_kernels": kernel_avg * 1e3,
                          "download_d2h": t_download * 1e3},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "binding": "dependency latency (LDS exchange + barriers + fp64 issue) of one workgroup per agent; "
-                                    "the working set is on-chip: `frac` is the NOMINAL SURVEY 8(d) figure (it prices every "
-                                    "iteration as if factor, rows and iterate streamed from HBM, and passes 1.0 as the kernel "
-                                    "gets faster); of the real resources HBM is the closest to its peak (hbm_counter_frac), "
-                                    "then fp64 issue and LDS (fp64.frac, lds.frac)",
-                         "fp64": {"achieved": flops_step / kernel_avg / 1e12, "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
-                                  "frac": flops_step / kernel_avg / 1e12 / FP64_PEAK_TF,
-                                  "flop_per_agent_iteration": "718 Nt + 88 K + 2592 (ADMM iterations only)"},
-                         "lds": {"achieved": lds_bytes_step / kernel_avg / 1e12, "peak": LDS_PEAK_TBS, "unit": "TB/s",
-                                 "frac": lds_bytes_step / kernel_avg / 1e12 / LDS_PEAK_TBS,
-                                 "bytes_per_agent_iteration": "8 (139 Nt + 42 K + 1440) (ADMM iterations only)"},
-                         "hbm_counter_frac": hbm_frac, "valu_fp64_issue_frac": valu_frac, "pmc_source": pmc_src,
-                         "kernel": "dsqp_agent_kernel<%d, %d, true>" % (dom["threads"], dom["residency_mode"]),
-                         "kernel_avg_ms": dom_avg * 1e3, "algorithmic_bytes_per_launch": gbytes[gd],
-                         "all_kernels": {"algorithmic_bytes_per_step": float(bytes_agent.sum()),
-                                         "avg_ms": kernel_avg * 1e3,
-                                         "achieved": float(bytes_agent.sum()) / kernel_avg / 1e9}},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world_size == 1:
             from tests import oracle_lib

@@ -1,0 +1,15 @@
+import os, sys, subprocess
+CODE = r"""
+import os, sys
+sys.path.insert(0, '.')
+from csdotrajectoryplanning_amd import _lib, workloads
+V = sys.argv[1]
+_lib.LIB_PATH = os.path.abspath(V)
+from csdotrajectoryplanning_amd.solver import DsqpHandle
+w, _ = workloads.map100_world(0)
+h = DsqpHandle(0); h.upload([w]); h.run(); ks = min(h.run() for _ in range(3)); s = h.download()[0]
+it = max(int(s.admm_iters.max()), 1)
+print('%-44s kernel %.2f ms  iters/agent %d  -> %.2f us per iteration' % (V, ks * 1e3, it, ks * 1e6 / it))
+"""
+for v in sys.argv[1:]:
+    subprocess.run([sys.executable, "-c", CODE, v])

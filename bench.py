@@ -380,14 +380,41 @@ def main():
             t_b0 = time.perf_counter()
             list(ex.map(_bridge, whole))
             t_bridge = time.perf_counter() - t_b0
-        e2e = {"total_ms": tot * 1e3, "bridge_device_batch_ms": t_bridge_dev * 1e3, "upload_pack_h2d_ms": t_upload * 1e3,
+        # ---- the same DO phase STREAMED in chunks of worlds (DsqpHandle.do_phase_stream: host bridge + packing + H2D of chunk
+        # k + 1 under the solve of chunk k on csdo_dsqp_create_shared handles, results of a chunk back under the later solves)
+        streamed = None
+        if len(whole) == len(worlds) and len(worlds) >= 3:
+            out_s, best_s = None, None
+            for _ in range(4):                 # (first pass: device buffers and page-locked staging of the chunk handles)
+                sols_s, tm = h.do_phase_stream(items, w0.veh, w0.parm, out=out_s)
+                out_s = sols_s
+                if best_s is None or tm["total"] < best_s["total"]:
+                    best_s = tm
+            same = all(np.array_equal(a_.solutions, b_.solutions) and np.array_equal(a_.admm_iters, b_.admm_iters)
+                       for a_, b_ in zip(sols_s, sols))
+            streamed = {"total_ms": best_s["total"] * 1e3, "first_launch_ms": best_s["first_launch"] * 1e3,
+                        "kernels_done_ms": best_s["kernels_done"] * 1e3,
+                        "chunks": [{"worlds": c_["worlds"], "bridge_host_ms": c_["bridge"] * 1e3,
+                                    "upload_pack_h2d_ms": c_["upload"] * 1e3, "kernels_ms": c_["kernel"] * 1e3}
+                                   for c_ in best_s["chunks"]],
+                        "agent_qp_iterations_per_sec": iters_step / best_s["total"],
+                        "results_equal_the_resident_batch": bool(same),
+                        "note": "best of 3 after a first pass; host wall clock from the coarse paths to the results in the "
+                                "caller's arrays; chunk k + 1 is bridged (host threads), packed and copied under chunk k's solve"}
+        e2e = {"total_ms": (streamed["total_ms"] if streamed else tot * 1e3),
+               "streamed": streamed,
+               "single_launch_total_ms": tot * 1e3,
+               "bridge_device_batch_ms": t_bridge_dev * 1e3, "upload_pack_h2d_ms": t_upload * 1e3,
                "solve_kernels_ms": t_k * 1e3, "solve_host_wall_ms": t_kw * 1e3, "download_d2h_scatter_ms": t_dl * 1e3,
                "upload_first_call_ms": t_upload_first * 1e3,
                "library_breakdown_ms": {k: v * 1e3 for k, v in xfer.items()},
                "bridge_host_threads_ms": t_bridge * 1e3, "bridge_host_threads": nthr,
-               "agent_qp_iterations_per_sec": iters_step / tot,
+               "agent_qp_iterations_per_sec": iters_step / (streamed["total_ms"] * 1e-3 if streamed else tot),
+               "agent_qp_iterations_per_sec_single_launch": iters_step / tot,
                "note": "PCIe-inclusive DO phase of rank 0's batch, best of 3, host wall clock from the coarse paths to the "
-                       "results in the caller's arrays; never `value`"}
+                       "results in the caller's arrays; never `value`.  total_ms = the streamed form when the batch has at "
+                       "least three whole worlds (`streamed`), else the single launch; the stage times below are the single "
+                       "launch's (device bridge of all worlds, pack + H2D, kernels, D2H + scatter, one after the other)"}
 
     # ---- the authors' own acceptance of a result: the trajectory validator (device kernel), per world
     validation = None

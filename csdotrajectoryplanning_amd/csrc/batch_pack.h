@@ -33,6 +33,42 @@ struct HostBatch {
 
 inline int fac_stride(int Nt) { return (Nt + 1) & ~1; }
 
+// body(i) for i in [0, n) on up to max_threads host threads (the calling thread is one of them).  Nothing escapes: a thread
+// that cannot be created (the caller's cgroup may cap them) just is not there - the started ones take its share -, a body that
+// throws (std::bad_alloc in a growing vector) is recorded, every started thread is joined on every path.  Returns CSDO_OK, or
+// CSDO_ENOMEM if a body threw.
+template <class F>
+inline int parallel_for(const int n, const int max_threads, F&& body) {
+  std::atomic<int> next{0}, failed{0};
+  auto run = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      try {
+        body(i);
+      } catch (...) {
+        failed.store(1);
+      }
+    }
+  };
+  const int n_thr = std::max(1, std::min({n, max_threads, (int)std::thread::hardware_concurrency()}));
+  struct Joiner {
+    std::vector<std::thread> thr;
+    ~Joiner() {
+      for (auto& t : thr)
+        if (t.joinable()) t.join();
+    }
+  } pool;
+  try {
+    pool.thr.reserve((size_t)n_thr);
+    for (int k = 1; k < n_thr; ++k) pool.thr.emplace_back(run);
+  } catch (...) {   // std::system_error (thread limit) / std::bad_alloc: go on with the threads there are
+  }
+  run();
+  for (auto& t : pool.thr) t.join();
+  return failed.load() ? CSDO_ENOMEM : CSDO_OK;
+}
+
 inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   SolverParams s{};
   s.f2x = v.f2x;
@@ -115,11 +151,9 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
   hb.rows_total = cur.rows;
   hb.fac_total = cur.fac;
   hb.steps_total = cur.steps;
-  std::atomic<int> next{0}, err{CSDO_OK}, max_planes{0};
-  auto fill = [&]() {
-    for (;;) {
-      const int w = next.fetch_add(1);
-      if (w >= n_worlds) break;
+  std::atomic<int> err{CSDO_OK}, max_planes{0};
+  auto fill = [&](const int w) {
+    {
       const csdo_problem& W = worlds[w];
       const Off& o = off[w];
       WorldDesc wd{};
@@ -226,16 +260,9 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
       }
     }
   };
-  const int n_thr = std::max(1, std::min({n_worlds, 16, (int)std::thread::hardware_concurrency()}));
-  if (n_thr == 1) {
-    fill();
-  } else {
-    std::vector<std::thread> pool;
-    for (int k = 0; k < n_thr; ++k) pool.emplace_back(fill);
-    for (auto& t : pool) t.join();
-  }
+  const int prc = parallel_for(n_worlds, 16, fill);
   hb.max_planes = max_planes.load();
-  return err.load();
+  return err.load() != CSDO_OK ? err.load() : prc;
 }
 
 // Scatter packed outputs back into per-world csdo_result buffers and aggregate the solver status the way
@@ -244,11 +271,8 @@ inline void unpack_results(const HostBatch& hb, const csdo_problem* worlds, int 
                            const double* corr, const int32_t* sqp_iters, const int32_t* admm_iters,
                            const int32_t* last_status, const int32_t* static_legal, csdo_result* results) {
   // worlds are independent: scattered by a few host threads (57 MB for the 3000-agent batch, first touch of the caller's pages)
-  std::atomic<int> next{0};
-  auto scatter = [&]() {
-   for (;;) {
-    const int w = next.fetch_add(1);
-    if (w >= n_worlds) break;
+  auto scatter = [&](const int w) {
+   {
     const int a0 = hb.world_first_agent[w], a1 = hb.world_first_agent[w + 1];
     csdo_result& R = results[w];
     bool any_bad = false;
@@ -273,14 +297,7 @@ inline void unpack_results(const HostBatch& hb, const csdo_problem* worlds, int 
     (void)worlds;
    }
   };
-  const int n_thr = std::max(1, std::min({n_worlds, 16, (int)std::thread::hardware_concurrency()}));
-  if (n_thr == 1) {
-    scatter();
-  } else {
-    std::vector<std::thread> pool;
-    for (int k = 0; k < n_thr; ++k) pool.emplace_back(scatter);
-    for (auto& t : pool) t.join();
-  }
+  (void)parallel_for(n_worlds, 16, scatter);
 }
 
 }  // namespace csdo

@@ -94,6 +94,9 @@ struct csdo_handle_s {
   int64_t limit_bytes = 0;
   double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
   DeviceBatch dev{};
+  bool borrowed = false;       // csdo_dsqp_create_shared: the streams belong to another handle (never destroyed here)
+  bool run_pending = false;    // csdo_dsqp_run_async has been called and csdo_dsqp_wait has not
+  std::vector<char> pending_second;   // which groups of the pending run have a second launch
 };
 
 #define HIP_OK(expr, code)                 \
@@ -236,9 +239,42 @@ int csdo_dsqp_create(csdo_handle* out, int device_ordinal) {
   return CSDO_OK;
 }
 
+// A second (third, ...) batch in flight on the same GPU: a handle with device buffers and events of its own whose launches go to
+// the PARENT's four streams, starting at stream `lane` (HIP maps streams onto four hardware queues in the order of their
+// creation and kernels that share a queue run one after the other: handles that each created four streams would collide on
+// them).  Its groups launch all their persistent workgroups at once (no second launch): they queue up behind the workgroups
+// of the batches in front and take the CUs those release.  The parent must outlive it.
+int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane) {
+  if (!out || !parent || lane < 0) return CSDO_EINVAL;
+  *out = nullptr;
+  HIP_OK(hipSetDevice(parent->device), CSDO_ENODEV);
+  while (parent->side.size() < 3) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CSDO_EDEVICE;
+    parent->side.push_back(s);
+  }
+  csdo_handle h = new (std::nothrow) csdo_handle_s();
+  if (!h) return CSDO_ENOMEM;
+  h->device = parent->device;
+  h->n_cu = parent->n_cu;
+  h->min_mode = parent->min_mode;
+  h->borrowed = true;
+  const hipStream_t four[4] = {parent->stream, parent->side[0], parent->side[1], parent->side[2]};
+  h->stream = four[lane & 3];
+  for (int k = 1; k < 4; ++k) h->side.push_back(four[(lane + k) & 3]);
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    delete h;
+    return CSDO_ENODEV;
+  }
+  *out = h;
+  return CSDO_OK;
+}
+
 void csdo_dsqp_destroy(csdo_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->run_pending) (void)hipEventSynchronize(h->ev1);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
                     &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->queues, &h->box_pts,
@@ -249,14 +285,15 @@ void csdo_dsqp_destroy(csdo_handle h) {
   h->stage_down.release();
   h->bridge_up.release();
   h->bridge_down.release();
-  for (hipStream_t s : h->side) (void)hipStreamDestroy(s);
+  if (!h->borrowed)
+    for (hipStream_t s : h->side) (void)hipStreamDestroy(s);
   for (hipEvent_t e : h->g_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_end) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_zeroed) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->g_end2) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && !h->borrowed) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -289,7 +326,7 @@ int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds
   return guarded([&]() { return upload_impl(h, worlds, n_worlds); });
 }
 static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
-  if (!h) return CSDO_EINVAL;
+  if (!h || h->run_pending) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   h->uploaded = false;
   h->limit_world = h->limit_agent = -1;
@@ -389,6 +426,12 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
       // (the first group is the one whose agents run longest: its share is sized for them and it hands its CUs over as
       // its queue drains; a second launch of it was observed to take CUs ahead of the later groups' first launches)
       G.elastic = std::max(0, std::min(cap_cu * per_cu, G.count) - G.primary);
+      // no stream is left for second launches with more than three groups, and none is wanted behind another batch's
+      // workgroups: the one launch then asks for every workgroup the group can use and the hardware starts them as CUs free up
+      if (h->groups.size() > 3 || h->borrowed) {
+        G.primary = std::min(cap_cu * per_cu, G.count);
+        G.elastic = 0;
+      }
       left -= n;
     }
   }
@@ -433,8 +476,12 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   return CSDO_OK;
 }
 
-int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
-  if (!h || !h->uploaded) return CSDO_EINVAL;
+// Enqueues the solve of the uploaded batch and returns: every group's launches, forked from and joined back into the
+// caller's stream (or the handle's).  csdo_dsqp_wait blocks until it is done and collects the timings; until then the batch
+// must not be uploaded again or downloaded.  Work enqueued on the same stream afterwards (a copy of the device results,
+// a collective) is ordered behind the solve.
+int csdo_dsqp_run_async(csdo_handle h, void* hip_stream) {
+  if (!h || !h->uploaded || h->run_pending) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   // after the fork an error must not leave side streams running behind the caller's back: drain the device first
 #define RUN_OK(expr)                      \
@@ -459,24 +506,33 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   }
   // second launches: same queues, workgroups that start on CUs other groups release; the first group's comes last so
   // that it does not take CUs ahead of the later groups' first launches
-  std::vector<char> second(ng, 0);
+  h->pending_second.assign(ng, 0);
   for (int g = ng - 1; g >= 0; --g) {
-    if (h->groups[g].elastic <= 0 || ng > 3) continue;
+    if (h->groups[g].elastic <= 0 || ng > 3 || h->borrowed) continue;
     hipStream_t es = ng == 1 ? h->side[0] : (ng == 2 ? h->side[1 + g] : h->side[2]);   // (what the first launches leave)
     RUN_OK(hipStreamWaitEvent(es, h->g_zeroed[g], 0));
     RUN_OK(launch_dsqp(h->dev, h->groups[g], h->groups[g].elastic, es));
     RUN_OK(hipEventRecord(h->g_end2[g], es));
     RUN_OK(hipStreamWaitEvent(s, h->g_end2[g], 0));
-    second[g] = 1;
+    h->pending_second[g] = 1;
   }
   for (int g = 1; g < ng; ++g) RUN_OK(hipStreamWaitEvent(s, h->g_end[g], 0));   // join
   RUN_OK(hipEventRecord(h->ev1, s));
+  h->run_pending = true;
+  return CSDO_OK;
+}
+
+int csdo_dsqp_wait(csdo_handle h) {
+  if (!h || !h->run_pending) return CSDO_EINVAL;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  h->run_pending = false;
   RUN_OK(hipEventSynchronize(h->ev1));
+  const int ng = (int)h->groups.size();
   float ms = 0.f;
   for (int g = 0; g < ng; ++g) {
     RUN_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end[g]));
     h->groups[g].seconds = (double)ms * 1e-3;
-    if (second[g]) {   // the group is done when both of its launches are
+    if (h->pending_second[g]) {   // the group is done when both of its launches are
       RUN_OK(hipEventElapsedTime(&ms, h->g_begin[g], h->g_end2[g]));
       h->groups[g].seconds = std::max(h->groups[g].seconds, (double)ms * 1e-3);
     }
@@ -485,6 +541,11 @@ int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
   h->last_kernel_s = (double)ms * 1e-3;
 #undef RUN_OK
   return CSDO_OK;
+}
+
+int csdo_dsqp_run(csdo_handle h, void* hip_stream) {
+  const int rc = csdo_dsqp_run_async(h, hip_stream);
+  return rc != CSDO_OK ? rc : csdo_dsqp_wait(h);
 }
 
 double csdo_dsqp_last_kernel_seconds(csdo_handle h) { return h ? h->last_kernel_s : 0.0; }
@@ -537,7 +598,7 @@ int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
   return guarded([&]() { return download_impl(h, results, n_worlds); });
 }
 static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds) {
-  if (!h || !h->uploaded || !results || n_worlds != h->n_worlds) return CSDO_EINVAL;
+  if (!h || !h->uploaded || h->run_pending || !results || n_worlds != h->n_worlds) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   const HostBatch& hb = h->hb;
   const size_t Na = hb.agents.size();
@@ -706,20 +767,11 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
     std::vector<BridgeCentres> C((size_t)n_worlds);
     std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
     for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));
+    // (parallel_for, batch_pack.h: a body that throws or a thread that cannot be created never unwinds through joinable threads)
     auto pool = [&](auto&& body) {
-      const int n_thr = std::max(1, std::min({n_worlds, 16, (int)std::thread::hardware_concurrency()}));
-      std::atomic<int> next{0};
-      auto run = [&]() {
-        for (;;) {
-          const int w = next.fetch_add(1);
-          if (w >= n_worlds) break;
-          body(w);
-        }
-      };
-      std::vector<std::thread> thr;
-      for (int k = 1; k < n_thr; ++k) thr.emplace_back(run);
-      run();
-      for (auto& t : thr) t.join();
+      if (parallel_for(n_worlds, 16, body) != CSDO_OK)
+        for (int w = 0; w < n_worlds; ++w)
+          if (rcs[w] == CSDO_OK) rcs[w] = CSDO_ENOMEM;
     };
     auto fail = [&](int code) {
       (void)hipStreamSynchronize(h->stream);   // pending copies may still read the staging buffers / write the results
@@ -749,6 +801,8 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
       const std::vector<float>* src[8] = {&C[w].xf, &C[w].yf, &C[w].xr, &C[w].yr, &C[w].xc, &C[w].yc, &C[w].cs, &C[w].sn};
       for (int k = 0; k < 8; ++k) std::memcpy(up + cen_off[w] + k * NN[w], src[k]->data(), NN[w] * sizeof(float));
     });
+    for (int w = 0; w < n_worlds; ++w)
+      if (rcs[w] != CSDO_OK) return fail(rcs[w]);
     lap("stage centres");
     hipStream_t s = h->stream;
     HIP_OK(hipMemcpyAsync(h->k0_centres.p, up, cen_off[n_worlds] * sizeof(float), hipMemcpyHostToDevice, s), fail(CSDO_EDEVICE));
@@ -809,10 +863,31 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
       if (rcs[w] != CSDO_OK) return fail(rcs[w]);
     lap("planes (host pool)");
     return CSDO_OK;
-  } catch (const std::bad_alloc&) {
+  } catch (...) {   // (allocation of the bookkeeping vectors: every outs[w] released and zeroed, as on the other error paths)
+    (void)hipStreamSynchronize(h->stream);
+    for (int w = 0; w < n_worlds; ++w) bridge_free(&outs[w]);
     return CSDO_ENOMEM;
+  }
+}
+
+// The host bridge for a batch of worlds: csdo_preprocess per world on a pool of host threads (no device work: it runs beside a
+// solve that occupies every CU - the streamed DO phase prepares its next chunk of worlds with it).  Outputs as csdo_preprocess.
+int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const int32_t* const* actions,
+                          const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
+                          const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs) {
+  if (n_worlds < 1 || !states || !actions || !path_off || !Na || !goals || !veh || !parm || !outs) return CSDO_EINVAL;
+  try {
+    std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
+    for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));
+    int rc = parallel_for(n_worlds, 16, [&](int w) {
+      rcs[w] = bridge_preprocess(states[w], actions[w], path_off[w], Na[w], goals[w], veh, parm, &outs[w]);
+    });
+    for (int w = 0; w < n_worlds && rc == CSDO_OK; ++w) rc = rcs[w];
+    if (rc != CSDO_OK)
+      for (int w = 0; w < n_worlds; ++w) bridge_free(&outs[w]);
+    return rc;
   } catch (...) {
-    return CSDO_EDEVICE;
+    return CSDO_ENOMEM;
   }
 }
 
@@ -832,24 +907,29 @@ static int validate_impl(csdo_handle h, const double* solutions, int32_t Na, int
   if ((rc = h->val_sol.ensure(b_sol)) != CSDO_OK) return rc;
   if ((rc = h->val_obs.ensure(b_obs)) != CSDO_OK) return rc;
   if ((rc = h->val_out.ensure(6 * sizeof(unsigned long long))) != CSDO_OK) return rc;
+  if (frames_per_move && (rc = h->val_frames.ensure((size_t)Na * n_frames * 6 * sizeof(double))) != CSDO_OK) return rc;
   hipStream_t s = h->stream;
+  // (from here on copies out of the caller's pageable arrays and out of `init` below are in flight: no return without draining the stream)
+  auto drained = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    return code;
+  };
   const unsigned long long none = ~0ull;
   unsigned long long init[6] = {0ull, none, 0ull, none, 0ull, none}, res[6];
-  HIP_OK(hipMemcpyAsync(h->val_sol.p, solutions, b_sol, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
-  if (n_obs) HIP_OK(hipMemcpyAsync(h->val_obs.p, obstacles, b_obs, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(h->val_out.p, init, sizeof(init), hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(h->val_sol.p, solutions, b_sol, hipMemcpyHostToDevice, s), drained(CSDO_EDEVICE));
+  if (n_obs) HIP_OK(hipMemcpyAsync(h->val_obs.p, obstacles, b_obs, hipMemcpyHostToDevice, s), drained(CSDO_EDEVICE));
+  HIP_OK(hipMemcpyAsync(h->val_out.p, init, sizeof(init), hipMemcpyHostToDevice, s), drained(CSDO_EDEVICE));
   const double* poses = (const double*)h->val_sol.p;
   if (frames_per_move) {
-    if ((rc = h->val_frames.ensure((size_t)Na * n_frames * 6 * sizeof(double))) != CSDO_OK) return rc;
     if (expand_frames_launch((const double*)h->val_sol.p, Na, Nt, frames_per_move, (double*)h->val_frames.p, s) != hipSuccess)
-      return CSDO_EDEVICE;
+      return drained(CSDO_EDEVICE);
     poses = (const double*)h->val_frames.p;
   }
   const double half_shift = 0.5 * (veh->LF - veh->LB), hl = 0.5 * (veh->LF + veh->LB) + margin, hw = 0.5 * veh->car_width + margin;
   if (validate_launch(poses, Na, (int)n_frames, (const double*)h->val_obs.p, n_obs, half_shift, hl, hw, dimx, dimy,
                       dimx > 0 && dimy > 0, (unsigned long long*)h->val_out.p, s) != hipSuccess)
-    return CSDO_EDEVICE;
-  HIP_OK(hipMemcpyAsync(res, h->val_out.p, sizeof(res), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    return drained(CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(res, h->val_out.p, sizeof(res), hipMemcpyDeviceToHost, s), drained(CSDO_EDEVICE));
   HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
   out->vehicle_collisions = (int64_t)res[0];
   out->obstacle_collisions = (int64_t)res[2];

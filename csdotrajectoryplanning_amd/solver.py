@@ -16,13 +16,28 @@ from .problem import Solution, World, bridge_to_world, bridge_views
 class DsqpHandle:
     """Owns one csdo_handle (device buffers + stream) on one GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _parent=None, _lane=0):
         self._h = C.c_void_p()
-        check(lib().csdo_dsqp_create(C.byref(self._h), int(device)), "csdo_dsqp_create")
+        if _parent is None:
+            check(lib().csdo_dsqp_create(C.byref(self._h), int(device)), "csdo_dsqp_create")
+        else:
+            check(lib().csdo_dsqp_create_shared(C.byref(self._h), _parent._h, int(_lane)), "csdo_dsqp_create_shared")
         self.device = int(device)
         self._keep = None
+        self._parent = _parent            # (keeps the owner of the streams alive)
+        self._children = {}
+
+    def shared(self, lane):
+        """A handle for a further batch in flight on this GPU (csdo_dsqp_create_shared): own device buffers, this handle's
+        streams starting at `lane`.  Cached per lane; closed with this handle."""
+        if lane not in self._children:
+            self._children[lane] = DsqpHandle(self.device, _parent=self, _lane=lane)
+        return self._children[lane]
 
     def close(self):
+        for c in list(getattr(self, "_children", {}).values()):
+            c.close()
+        self._children = {}
         if self._h:
             lib().csdo_dsqp_destroy(self._h)
             self._h = C.c_void_p()
@@ -56,6 +71,63 @@ class DsqpHandle:
     def run(self, stream=None):
         check(lib().csdo_dsqp_run(self._h, C.c_void_p(stream) if stream else None), "csdo_dsqp_run")
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
+
+    def run_async(self, stream=None):
+        """csdo_dsqp_run_async: enqueue the solve and return; wait() collects it."""
+        check(lib().csdo_dsqp_run_async(self._h, C.c_void_p(stream) if stream else None), "csdo_dsqp_run_async")
+
+    def wait(self):
+        check(lib().csdo_dsqp_wait(self._h), "csdo_dsqp_wait")
+        return lib().csdo_dsqp_last_kernel_seconds(self._h)
+
+    def do_phase_stream(self, items, veh, parm, fractions=(0.08, 0.27, 0.65), out=None, order=None):
+        """The DO phase of csdo.cc:111-148 for a batch of worlds, streamed in chunks of worlds: the host bridge, the packing
+        and the H2D copies of chunk k + 1 run under the solve of chunk k (csdo_dsqp_create_shared / csdo_dsqp_run_async), the
+        results of a chunk come back under the solve of the later ones.  The chunks grow (a small first one starts the GPU
+        within a millisecond or two; most agents are in the last one, where the launcher's longest-first order still has
+        a large pool to work with - an agent that runs long and starts late is what a streamed batch can lose on).
+        items: per world (states, actions, path_off, goals, dimx, dimy, obstacles); order: the worlds in the order they
+        should be started (default: as given); out: what a previous call returned first (its arrays are written again).
+        Returns (solutions in the order of `items`, dict of host-side timings in seconds)."""
+        import time
+        n = len(items)
+        idx = list(range(n)) if order is None else [int(i) for i in order]
+        fr = [f for f in fractions if f > 0]
+        fr = fr[-min(len(fr), n, 4):]                      # at most four batches in flight (four streams), never an empty chunk
+        cuts = [0]
+        tot = float(sum(fr))
+        acc = 0.0
+        for c, f in enumerate(fr):
+            acc += f
+            hi = n if c == len(fr) - 1 else max(cuts[-1] + 1, min(n - (len(fr) - 1 - c), int(round(n * acc / tot))))
+            cuts.append(hi)
+        t0 = time.perf_counter()
+        timing = {"first_launch": None, "chunks": []}
+        inflight = []
+        for c in range(len(fr)):
+            part = idx[cuts[c]:cuts[c + 1]]
+            hc = self.shared(c)
+            tb = time.perf_counter()
+            bridged = interpolate_and_planes_batch_host([items[i] for i in part], veh, parm)
+            tu = time.perf_counter()
+            hc.upload([b[0] for b in bridged])
+            tr = time.perf_counter()
+            hc.run_async()
+            if timing["first_launch"] is None:
+                timing["first_launch"] = time.perf_counter() - t0
+            timing["chunks"].append({"worlds": len(part), "bridge": tu - tb, "upload": tr - tu})
+            inflight.append((hc, part))
+        sols = [None] * n
+        kernel_end = 0.0
+        for (hc, part), info in zip(inflight, timing["chunks"]):
+            info["kernel"] = hc.wait()
+            kernel_end = time.perf_counter() - t0
+            got = hc.download(out=None if out is None else [out[i] for i in part])
+            for i, s_ in zip(part, got):
+                sols[i] = s_
+        timing["kernels_done"] = kernel_end
+        timing["total"] = time.perf_counter() - t0
+        return sols, timing
 
     def transfer_seconds(self):
         """Host seconds of the last upload / download: dict(pack, stage, h2d, d2h, unpack)."""
@@ -123,17 +195,7 @@ class DsqpHandle:
         """csdo_preprocess_device_batch: items = [(states, actions, path_off, goals, dimx, dimy, obstacles), ...], one per world;
         returns [(World, pairs, initial_inter_legal), ...] - per world what interpolate_and_planes returns."""
         n = len(items)
-        keep = []
-        st_p, ac_p, po_p, g_p = (abi.c_double_p * n)(), (abi.c_int32_p * n)(), (abi.c_int32_p * n)(), (abi.c_double_p * n)()
-        na = np.zeros(n, np.int32)
-        for k, (st, ac, po, G, _, _, _) in enumerate(items):
-            st = np.ascontiguousarray(st, dtype=np.float64)
-            ac = np.ascontiguousarray(ac, dtype=np.int32)
-            po = np.ascontiguousarray(po, dtype=np.int32)
-            G = np.ascontiguousarray(G, dtype=np.float64)
-            keep.append((st, ac, po, G))
-            st_p[k], ac_p[k], po_p[k], g_p[k] = abi.as_double_p(st), abi.as_int32_p(ac), abi.as_int32_p(po), abi.as_double_p(G)
-            na[k] = len(po) - 1
+        keep, st_p, ac_p, po_p, na, g_p = _marshal_paths(items)
         outs = (abi.BridgeOut * n)()
         check(lib().csdo_preprocess_device_batch(self._h, n, st_p, ac_p, po_p, abi.as_int32_p(na), g_p, C.byref(veh),
                                                  C.byref(parm), outs), "csdo_preprocess_device_batch")
@@ -204,6 +266,34 @@ class SolverDSQP:
 
     def get_initial_static_legal(self):
         return bool(self._sol.initial_static_legal)
+
+
+def _marshal_paths(items):
+    n = len(items)
+    keep = []
+    st_p, ac_p, po_p, g_p = (abi.c_double_p * n)(), (abi.c_int32_p * n)(), (abi.c_int32_p * n)(), (abi.c_double_p * n)()
+    na = np.zeros(n, np.int32)
+    for k, (st, ac, po, G, _, _, _) in enumerate(items):
+        st = np.ascontiguousarray(st, dtype=np.float64)
+        ac = np.ascontiguousarray(ac, dtype=np.int32)
+        po = np.ascontiguousarray(po, dtype=np.int32)
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        keep.append((st, ac, po, G))
+        st_p[k], ac_p[k], po_p[k], g_p[k] = abi.as_double_p(st), abi.as_int32_p(ac), abi.as_int32_p(po), abi.as_double_p(G)
+        na[k] = len(po) - 1
+    return keep, st_p, ac_p, po_p, na, g_p
+
+
+def interpolate_and_planes_batch_host(items, veh, parm):
+    """csdo_preprocess_batch: the host bridge of every world of `items` (as DsqpHandle.interpolate_and_planes_batch takes them)
+    on a pool of host threads, no device work.  Returns [(World, pairs, initial_inter_legal), ...], views of library memory."""
+    n = len(items)
+    keep, st_p, ac_p, po_p, na, g_p = _marshal_paths(items)
+    outs = (abi.BridgeOut * n)()
+    check(lib().csdo_preprocess_batch(n, st_p, ac_p, po_p, abi.as_int32_p(na), g_p, C.byref(veh), C.byref(parm), outs),
+          "csdo_preprocess_batch")
+    del keep
+    return [bridge_views(outs[k], lib().csdo_bridge_free, it[4], it[5], it[6], veh, parm) for k, it in enumerate(items)]
 
 
 def estimate_work(worlds):

@@ -141,6 +141,20 @@ int csdo_dsqp_last_limit(csdo_handle h, int32_t* world, int32_t* agent, int64_t*
  *   upload (H2D, builds the device problem) -> run (kernels only, repeatable) -> download (D2H). */
 int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds);
 int csdo_dsqp_run(csdo_handle h, void* hip_stream /* hipStream_t or NULL for the handle's stream */);
+/* The same in two halves: csdo_dsqp_run_async enqueues the solve (every launch group's kernels, forked from and joined back
+ * into the stream) and returns; csdo_dsqp_wait blocks until it is done and collects the timings.  Between the two the
+ * handle's batch must not be uploaded again or downloaded (CSDO_EINVAL); work the caller enqueues on the same stream in
+ * between - a copy of csdo_dsqp_device_solutions, a collective - is ordered behind the solve.  No reference counterpart
+ * (the reference's constructor blocks, sqp/dsqp_solver.cc:1133-1249). */
+int csdo_dsqp_run_async(csdo_handle h, void* hip_stream);
+int csdo_dsqp_wait(csdo_handle h);
+/* A further batch in flight on the same GPU: a handle with device buffers of its own whose launches go to `parent`'s
+ * streams, starting at stream `lane` (0..3; HIP serves streams from four hardware queues, and kernels that share a queue
+ * run one after the other - give batches in flight different lanes).  Its kernels queue up behind the workgroups of the
+ * batches launched before and take the CUs those release, so the preparation (bridge, packing, H2D) of one part of a job
+ * can run under the solve of the part before it: DO phase of csdo.cc:111-148 streamed in world chunks.  The parent must
+ * outlive the handle; destroy it with csdo_dsqp_destroy. */
+int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane);
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
 /* Device time of the last csdo_dsqp_run in seconds (HIP events on the launch stream) and the kernel's own name. */
 double csdo_dsqp_last_kernel_seconds(csdo_handle h);
@@ -208,6 +222,12 @@ int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* a
 int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* const* states, const int32_t* const* actions,
                                  const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
                                  const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs /* [n_worlds] */);
+/* csdo_preprocess for a batch of worlds on a pool of host threads, no device work (it runs beside a solve that occupies every
+ * CU: the streamed DO phase prepares its next chunk of worlds with it).  outs[w] as csdo_preprocess fills it; on error every
+ * outs[w] is released and zeroed. */
+int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const int32_t* const* actions,
+                          const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
+                          const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs);
 
 /* Front end (host): priority-based search, each agent planned by a spatiotemporal hybrid A* that yields to the agents
  * ranked above it.  starts / goals [Na][3] = x, y, yaw.  On success (status 1) the paths come back in exactly the layout

@@ -398,9 +398,12 @@ def main():
                                     "upload_pack_h2d_ms": c_["upload"] * 1e3, "kernels_ms": c_["kernel"] * 1e3}
                                    for c_ in best_s["chunks"]],
                         "agent_qp_iterations_per_sec": iters_step / best_s["total"],
+                        "in_chunks": bool(best_s["streamed"]),
                         "results_equal_the_resident_batch": bool(same),
                         "note": "best of 3 after a first pass; host wall clock from the coarse paths to the results in the "
-                                "caller's arrays; chunk k + 1 is bridged (host threads), packed and copied under chunk k's solve"}
+                                "caller's arrays; chunk k + 1 is bridged (host threads), packed and copied under chunk k's solve; "
+                                "a job of several kernel classes (in_chunks false) is bridged on the host pool and solved by "
+                                "one launch instead"}
         e2e = {"total_ms": (streamed["total_ms"] if streamed else tot * 1e3),
                "streamed": streamed,
                "single_launch_total_ms": tot * 1e3,

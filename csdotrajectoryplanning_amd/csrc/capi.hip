@@ -95,6 +95,7 @@ struct csdo_handle_s {
   double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
   DeviceBatch dev{};
   bool borrowed = false;       // csdo_dsqp_create_shared: the streams belong to another handle (never destroyed here)
+  hipStream_t four[4] = {nullptr, nullptr, nullptr, nullptr};   // ... the owner's four streams
   bool run_pending = false;    // csdo_dsqp_run_async has been called and csdo_dsqp_wait has not
   std::vector<char> pending_second;   // which groups of the pending run have a second launch
 };
@@ -260,6 +261,7 @@ int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane) 
   h->min_mode = parent->min_mode;
   h->borrowed = true;
   const hipStream_t four[4] = {parent->stream, parent->side[0], parent->side[1], parent->side[2]};
+  for (int k = 0; k < 4; ++k) h->four[k] = four[k];
   h->stream = four[lane & 3];
   for (int k = 1; k < 4; ++k) h->side.push_back(four[(lane + k) & 3]);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -268,6 +270,16 @@ int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane) 
     return CSDO_ENODEV;
   }
   *out = h;
+  return CSDO_OK;
+}
+
+// Re-points a shared handle at stream `lane` of its parent (its launch groups take lane, lane + 1, ... modulo four): a batch
+// with several launch groups needs as many streams, so the caller that keeps batches in flight deals the lanes out by the
+// group counts (csdo_dsqp_launch_groups) once the batches are uploaded.  Not while a run is pending.
+int csdo_dsqp_set_lane(csdo_handle h, int32_t lane) {
+  if (!h || !h->borrowed || h->run_pending || lane < 0) return CSDO_EINVAL;
+  h->stream = h->four[lane & 3];
+  for (int k = 1; k < 4; ++k) h->side[(size_t)k - 1] = h->four[(lane + k) & 3];
   return CSDO_OK;
 }
 

@@ -72,6 +72,9 @@ class DsqpHandle:
         check(lib().csdo_dsqp_run(self._h, C.c_void_p(stream) if stream else None), "csdo_dsqp_run")
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
 
+    def set_lane(self, lane):
+        check(lib().csdo_dsqp_set_lane(self._h, int(lane)), "csdo_dsqp_set_lane")
+
     def run_async(self, stream=None):
         """csdo_dsqp_run_async: enqueue the solve and return; wait() collects it."""
         check(lib().csdo_dsqp_run_async(self._h, C.c_void_p(stream) if stream else None), "csdo_dsqp_run_async")
@@ -80,7 +83,7 @@ class DsqpHandle:
         check(lib().csdo_dsqp_wait(self._h), "csdo_dsqp_wait")
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
 
-    def do_phase_stream(self, items, veh, parm, fractions=(0.08, 0.27, 0.65), out=None, order=None):
+    def do_phase_stream(self, items, veh, parm, fractions=(0.08, 0.27, 0.65), out=None, order=None, single_launch_if_mixed=True):
         """The DO phase of csdo.cc:111-148 for a batch of worlds, streamed in chunks of worlds: the host bridge, the packing
         and the H2D copies of chunk k + 1 run under the solve of chunk k (csdo_dsqp_create_shared / csdo_dsqp_run_async), the
         results of a chunk come back under the solve of the later ones.  The chunks grow (a small first one starts the GPU
@@ -88,6 +91,8 @@ class DsqpHandle:
         a large pool to work with - an agent that runs long and starts late is what a streamed batch can lose on).
         items: per world (states, actions, path_off, goals, dimx, dimy, obstacles); order: the worlds in the order they
         should be started (default: as given); out: what a previous call returned first (its arrays are written again).
+        single_launch_if_mixed: a job whose first chunk needs more than one kernel class is solved by ONE launch of all its
+        worlds on this handle instead (which replaces the batch this handle held).
         Returns (solutions in the order of `items`, dict of host-side timings in seconds)."""
         import time
         n = len(items)
@@ -102,8 +107,18 @@ class DsqpHandle:
             hi = n if c == len(fr) - 1 else max(cuts[-1] + 1, min(n - (len(fr) - 1 - c), int(round(n * acc / tot))))
             cuts.append(hi)
         t0 = time.perf_counter()
+        if single_launch_if_mixed:
+            # The horizon of a world is known from its coarse paths (sqp/inter_agent_cons.cc:320-325: the longest path, num_interpolation
+            # points inserted per move); horizons 129 .. 234 run in ONE kernel class (512 threads, everything in LDS).  Anything else
+            # makes a job of several classes: treated as the first chunk of one (the test below) and solved by one launch.
+            ni = int(parm.num_interpolation) + 1
+            nts = [ni * (int(np.max(np.diff(np.asarray(items[i][2])))) - 1) + 1 for i in idx]
+            mixed_by_horizon = not all(128 < nt <= 234 for nt in nts)
+        else:
+            mixed_by_horizon = False
         timing = {"first_launch": None, "chunks": []}
         inflight = []
+        next_lane = 0
         for c in range(len(fr)):
             part = idx[cuts[c]:cuts[c + 1]]
             hc = self.shared(c)
@@ -112,6 +127,31 @@ class DsqpHandle:
             tu = time.perf_counter()
             hc.upload([b[0] for b in bridged])
             tr = time.perf_counter()
+            # a batch's launch groups run side by side on streams of their own, and kernels that share a stream run one after the
+            # other: deal the four streams out by the group counts (a chunk that comes around to a stream still in use queues
+            # up behind an EARLIER, i.e. smaller, chunk's kernel)
+            ng = len(hc.launch_groups())
+            if c == 0 and (ng > 1 or mixed_by_horizon) and single_launch_if_mixed:
+                # Several kernel classes (workgroup sizes / residency modes) in the job: their CU shares are balanced per launch,
+                # and chunks of such launches in flight at once fragment the CUs (measured: map50 set 87 ms streamed against 59 ms,
+                # room set 115 against 68).  One launch of everything, on this handle, with the rest bridged at once.
+                rest = idx[cuts[1]:]
+                more = interpolate_and_planes_batch_host([items[i] for i in rest], veh, parm) if rest else []
+                tu2 = time.perf_counter()
+                self.upload([b[0] for b in bridged] + [b[0] for b in more])
+                tr2 = time.perf_counter()
+                kern = self.run()
+                kernel_end = time.perf_counter() - t0
+                allidx = part + rest
+                got = self.download(out=None if out is None else [out[i] for i in allidx])
+                sols = [None] * n
+                for i, s_ in zip(allidx, got):
+                    sols[i] = s_
+                return sols, {"first_launch": tr2 - t0, "kernels_done": kernel_end, "total": time.perf_counter() - t0,
+                              "streamed": False,
+                              "chunks": [{"worlds": n, "bridge": (tu - tb) + (tu2 - tr), "upload": tr2 - tu2, "kernel": kern}]}
+            hc.set_lane(next_lane)
+            next_lane = (next_lane + max(ng, 1)) % 4
             hc.run_async()
             if timing["first_launch"] is None:
                 timing["first_launch"] = time.perf_counter() - t0
@@ -127,6 +167,7 @@ class DsqpHandle:
                 sols[i] = s_
         timing["kernels_done"] = kernel_end
         timing["total"] = time.perf_counter() - t0
+        timing["streamed"] = True
         return sols, timing
 
     def transfer_seconds(self):

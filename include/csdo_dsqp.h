@@ -155,6 +155,10 @@ int csdo_dsqp_wait(csdo_handle h);
  * can run under the solve of the part before it: DO phase of csdo.cc:111-148 streamed in world chunks.  The parent must
  * outlive the handle; destroy it with csdo_dsqp_destroy. */
 int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane);
+/* Re-points a shared handle at stream `lane` of its parent; its launch groups take lane, lane + 1, ... (modulo four).  A batch
+ * with G launch groups (csdo_dsqp_launch_groups, known once it is uploaded) occupies G streams: deal the lanes out by those
+ * counts.  CSDO_EINVAL for a handle that owns its streams or while a run is pending. */
+int csdo_dsqp_set_lane(csdo_handle h, int32_t lane);
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds);
 /* Device time of the last csdo_dsqp_run in seconds (HIP events on the launch stream) and the kernel's own name. */
 double csdo_dsqp_last_kernel_seconds(csdo_handle h);

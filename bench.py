@@ -302,12 +302,26 @@ def main():
             fg = sharding.FlatGather(n_dbl, dist, dev)     # ranks differ in sum(Nt): padded to the largest
         tstream.synchronize()
 
+    # Sharded step: solve enqueued (csdo_dsqp_run_async), the copy out of the solver's buffer ordered behind it on the same stream,
+    # the all-gather on a SECOND stream behind that copy - so the collective of step k runs beside the solve of step k + 1 (the
+    # next copy into the send buffer waits for it).  The barrier / synchronize pair around the timed region covers both streams.
+    gstream = torch.cuda.Stream(device=dev) if fg is not None else None
+    collected = [None]
+
     def step():
-        ks = h.run(stream)
-        if fg is not None:
-            with torch.cuda.stream(tstream):
-                fg.gather(sol_dev)
-        return ks
+        if fg is None:
+            return h.run(stream)
+        h.run_async(stream)
+        with torch.cuda.stream(tstream):
+            if collected[0] is not None:
+                tstream.wait_event(collected[0])
+            fg.stage(sol_dev)
+            staged = tstream.record_event()
+        with torch.cuda.stream(gstream):
+            gstream.wait_event(staged)
+            fg.collect()
+            collected[0] = gstream.record_event()
+        return h.wait()
 
     for _ in range(args.warmup):
         step()
@@ -570,7 +584,8 @@ def main():
                                  if strong else
                                  "%d copies of the workload, agents sharded in contiguous blocks over %d ranks"
                                  % (copies, world_size))),
-                "collective": ("all_gather(final trajectories, device pointers) per step" +
+                "collective": ("all_gather(final trajectories, device pointers) per step, on a second stream: the gather of step k "
+                               "runs beside the solve of step k + 1" +
                                (" on a ONE-rank nccl group (--force-dist)" if world_size == 1 else "")) if sharded else "none",
                 "shard_balance": shard_balance,
                 "per_rank": per_rank,

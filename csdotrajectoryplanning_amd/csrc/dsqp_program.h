@@ -397,6 +397,15 @@ CSDO_FN double wave_shfl_down(double v, int off) {
 #endif
 
 #if defined(CSDO_LANE_MODE_DEVICE)
+// the value of lane + 1 of the wave (DPP wave_shl:1, supported on gfx950; the last lane reads 0)
+CSDO_FN double wave_next(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
+#if defined(CSDO_LANE_MODE_DEVICE)
 CSDO_FN double wave_shfl_xor(double v, int mask) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __shfl_xor(lo, mask, 64);

@@ -1163,8 +1163,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             });
           }
           const double s01 = a0 + a1;                                   // lane 0 of the row: a0 + a1, lane 1: a2 + a3, lane 2: a4 + a5
-          const double s0123 = s01 + wave_shfl_down(s01, 1);            // lane 0: (a0 + a1) + (a2 + a3)
-          const double tot = s0123 + wave_shfl_down(s01, 2);            // lane 0: ... + (a4 + a5)
+          // (the neighbours' sums by DPP wave_shl:1 - a register move -, not by __shfl_down: that is a ds_bpermute, an LDS round trip
+          //  each, two in a row on the critical path of every iteration)
+          const double up1 = wave_next(s01), up2 = wave_next(up1);       // s01 of lane + 1, of lane + 2
+          const double s0123 = s01 + up1;                               // lane 0: (a0 + a1) + (a2 + a3)
+          const double tot = s0123 + up2;                               // lane 0: ... + (a4 + a5)
           if (wl < 63 && r < n_tail && p2 == 0) {
             const int kn = r / 6, i = r - 6 * kn;
             sh.vec[(kn * h_tail) * LD_vec + i] = tot;

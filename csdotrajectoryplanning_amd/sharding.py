@@ -93,7 +93,16 @@ class FlatGather:
         self.out = torch.empty(ws * self.n_max, dtype=torch.float64, device=device)
 
     def gather(self, local):
+        self.stage(local)
+        return self.collect()
+
+    # The two halves of gather(), for a step that overlaps the collective with the NEXT solve: stage() on the stream the solve
+    # was launched on (the copy out of the solver's buffer is then ordered behind the solve, and the buffer is free for the
+    # next one), collect() on a second stream that waits for the copy; the next stage() must wait for that collect().
+    def stage(self, local):
         self.send[:self.n_local].copy_(local[:self.n_local])
+
+    def collect(self):
         self.dist.all_gather_into_tensor(self.out, self.send)
         return self.out.view(len(self.lengths), self.n_max)
 

@@ -37,13 +37,15 @@ def test_gpu_matches_golden_and_oracle(gpu_handle, oracle, veh_parm, name):
 
 def test_gpu_full_map50_agents25(gpu_handle, oracle, world_map50):
     world, info = world_map50
-    _check(oracle.solve(world, 8), gpu_handle.solve(world), allow_loose=1)
+    _check(oracle.solve(world, 8), gpu_handle.solve(world))
 
 
 def test_gpu_full_map100_agents50(gpu_handle, oracle, world_map100):
     world, info = world_map100
     got = gpu_handle.solve(world)
-    _check(oracle.solve(world, 8), got, allow_loose=3)
+    # (measured: agents 6 and 13 of ex0 end 8.0e-4 and 1.6e-4 from the oracle, boxes unchanged: two of the chain-sensitive agents of
+    #  tests/golden/chain_outliers_map100.json; every other agent within 1e-4)
+    _check(oracle.solve(world, 8), got, allow_loose=2)
     # size-independent properties at the full size
     x0 = world.x0_bar
     ok = got.last_status == 1
@@ -169,6 +171,29 @@ def test_gpu_long_horizons_use_the_wide_kernels(gpu_handle, oracle, veh_parm, L,
     _check(oracle.solve(w, 1), gpu_handle.solve(w))
     gpu_handle.upload([w])
     assert [(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()] == [(threads, mode)]
+
+
+@pytest.mark.parametrize("Nt", [385, 511, 512])
+def test_gpu_longest_horizons_with_inter_vehicle_rows(gpu_handle, oracle, veh_parm, Nt):
+    """The ends of the 1024-thread class with separating planes at work: its first horizon (385), the longest one the bridge can
+    produce (511 = 3 * 170 + 1) and CSDO_MAX_NT itself (512: the 514-step world cut to 512 timesteps, planes beyond dropped)."""
+    from csdotrajectoryplanning_amd import abi
+    from csdotrajectoryplanning_amd.problem import World
+    veh, parm = veh_parm
+    L = {385: 128, 511: 170, 512: 171}[Nt]
+    w = helpers.straight_line_world(veh, parm, Na=2, L=L, dim=700.0, spacing=3.5)
+    if Nt == 512:
+        assert w.Nt == 514 and abi.CSDO_MAX_NT == 512
+        keep, off = [], [0]
+        for a in range(w.Na):
+            p = w.planes[w.plane_off[a]:w.plane_off[a + 1]]
+            keep.append(p[p["t"] < 512])
+            off.append(off[-1] + len(keep[-1]))
+        w = World(np.ascontiguousarray(w.x0_bar[:, :512]), np.asarray(off, np.int32), np.concatenate(keep), w.dimx, w.dimy,
+                  w.obstacles, veh, parm)
+    assert w.Nt == Nt and w.plane_off[-1] > 2 * (Nt - 10)
+    _check(oracle.solve(w, 2), gpu_handle.solve(w))
+    assert [(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()] == [(1024, 3)]
 
 
 def test_gpu_fixed_corridor_mode_is_tight(gpu_handle, oracle, veh_parm):

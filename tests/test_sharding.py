@@ -68,7 +68,15 @@ def _batch_worker(rank, world_size, port, out_dir):
     sols = emu_lib.solve_batch(mine)
     flat = torch.from_numpy(np.concatenate([s.solutions.reshape(-1) for s in sols]))
     fg = FlatGather(flat.numel(), dist, torch.device("cpu"))
+    # the step's two halves (bench.py overlaps collect() of step k with the solve of step k + 1): what is gathered is what was
+    # staged, whatever the solver's buffer holds by the time the collective runs
+    live = flat.clone()
+    fg.stage(live)
+    live.zero_()                                   # "the next solve" overwrites the buffer
+    fg.collect()
+    staged_first = torch.cat(fg.parts()).clone()
     fg.gather(flat)
+    assert torch.equal(staged_first, torch.cat(fg.parts()))
     np.save(os.path.join(out_dir, f"flat_{rank}.npy"), torch.cat(fg.parts()).numpy())
     np.save(os.path.join(out_dir, f"counts_{rank}.npy"), np.array([sum(w.Na for w in mine)]))
     dist.barrier()

@@ -71,7 +71,8 @@ struct DeviceBatch {
 };
 
 constexpr int ROWS_WS_STRIDE = 9;   // doubles per inter row in rows_ws: 8 fields + room for the per-plane rhs shares
-constexpr int FAC_E_DOUBLES = 72;   // E_l + E_r per node, lane-major
+constexpr int FAC_E_DOUBLES = 108;  // per lane, lane-major: [0,36) and [72,108) the two 6x6 blocks the LANE multiplies in the solve (pair-split
+                                    // modes: dsqp_program.h; the long-horizon modes keep F_l of the NODE in [0,36)), [36,72) the node's coupling R / F_r
 constexpr int FAC_X_DOUBLES = 100;  // factor-time exchange per node: U_l(21) + U_r(21) + Rnew(36) + diagonal block (21, padded)
 constexpr int COLD_DOUBLES = 210;   // per-lane workspace slots (WsSlot in dsqp_program.h)
 

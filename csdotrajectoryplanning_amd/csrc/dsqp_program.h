@@ -92,6 +92,35 @@ __device__ __forceinline__ double csdo_one_if(const bool c, const double d) {
   if constexpr (ROLE != ROLE_ROW)                                                           \
     if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
       if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0)
+// Pair-split solve (agent_program, residency modes 0 and 1): EVERY thread of the solver half takes part, whatever Nt - the
+// cross-lane moves below need whole waves.  A block of such lanes is a sequence of steps; what one step hands to other lanes
+// (through the DPP moves of CSDO_XGET or through LDS) is read in the next one.  On the device the steps are straight-line code of
+// one wave (lock step; LDS instructions of a wave complete in order, so an in-wave exchange through LDS needs no barrier); the
+// lane-serial build closes the loop over the lanes at every CSDO_XSTEP and opens the next one.
+#define CSDO_XLANES(t) if constexpr (ROLE != ROLE_ROW) if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0)
+// lanes 0..5 of every solver wave behind which another wave starts at node s (< Nt): one component q each (sum of the partials that node takes from this wave)
+#define CSDO_HANDOVER_LANES(s, q) \
+  if constexpr (ROLE != ROLE_ROW) if (const int tt_ = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE), q = tt_ & 63, s = tt_ - q + 64; tt_ >= 0 && q < 6 && s < Nt)
+#define CSDO_XSTEP(t)               /* register hand-over (DPP): program order is all it needs */
+#define CSDO_XSTEP_LDS(t) csdo_wave_sync();   /* in-wave hand-over through LDS */
+__device__ __forceinline__ void csdo_wave_sync() {   // orders the wave's own LDS stores before its later LDS loads for the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// DPP controls (v_mov_b32_dpp): the source lane of lane i within its wave of 64
+#define CSDO_DPP_PAIR_EVEN 0xA0   /* quad_perm [0,0,2,2]: i & ~1 */
+#define CSDO_DPP_PAIR_ODD 0xF5    /* quad_perm [1,1,3,3]: i | 1  */
+#define CSDO_DPP_PAIR_SWAP 0xB1   /* quad_perm [1,0,3,2]: i ^ 1  */
+#define CSDO_DPP_PREV 0x138       /* wave_shr:1: i - 1, lane 0 reads 0.0 */
+#define CSDO_DPP_ROW_PLUS2 0x102  /* row_shl:2: i + 2 inside the row of 16 lanes (beyond it: 0.0) */
+template <int CTRL>
+__device__ __forceinline__ double csdo_dpp_f64(const double v) {   // (bound_ctrl: a lane without a source reads 0 - and no copy of an old value is made)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+#define CSDO_XGET(CTRL, fld, k) csdo_dpp_f64<CTRL>(V.fld[k])
 #define CSDO_LS(t) lanes_r
 #define CSDO_SS(t) lanes_s
 #define CSDO_SYNC() __syncthreads()
@@ -129,6 +158,27 @@ __device__ __forceinline__ double csdo_one_if(const bool c, const double d) {
 #define CSDO_TLANES_HOT(t) CSDO_TLANES(t)
 #define CSDO_TLANES_TOP(t) CSDO_TLANES(t)
 #define CSDO_STHREADS_HOT(t, nthr) CSDO_STHREADS(t, nthr)
+#define CSDO_XLANES(t) if constexpr (ROLE != ROLE_ROW) for (int t = 0; t < NtE; ++t)
+#define CSDO_HANDOVER_LANES(s, q) if constexpr (ROLE != ROLE_ROW) for (int s = 64; s < Nt; s += 64) for (int q = 0; q < 6; ++q)
+#define CSDO_XSTEP(t) } CSDO_XLANES(t) { SolvRegs& V = CSDO_SS(t);
+#define CSDO_XSTEP_LDS(t) CSDO_XSTEP(t)
+#define CSDO_DPP_PAIR_EVEN 0xA0
+#define CSDO_DPP_PAIR_ODD 0xF5
+#define CSDO_DPP_PAIR_SWAP 0xB1
+#define CSDO_DPP_PREV 0x138
+#define CSDO_DPP_ROW_PLUS2 0x102
+// what v_mov_b32_dpp does with these controls: source lane of lane t (waves of 64), -1: none (reads 0.0)
+inline int csdo_dpp_src(const int ctrl, const int t, const int n_lanes) {
+  const int lane = t & 63, base = t - lane;
+  int src = -1;
+  if (ctrl < 0x100) src = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl == 0x138) src = lane - 1;
+  else if (ctrl == 0x130) src = lane + 1 < 64 ? lane + 1 : -1;
+  else if (ctrl > 0x100 && ctrl <= 0x10F) src = ((lane & 15) + (ctrl & 15) < 16) ? lane + (ctrl & 15) : -1;
+  if (src < 0 || base + src >= n_lanes) return -1;
+  return base + src;
+}
+#define CSDO_XGET(CTRL, fld, k) (csdo_dpp_src(CTRL, t, NtE) >= 0 ? lanes_s[csdo_dpp_src(CTRL, t, NtE)].fld[k] : 0.0)
 #define CSDO_LS(t) lanes_r[t]
 #define CSDO_SS(t) lanes_s[t]
 #define CSDO_SYNC() ((void)0)
@@ -270,6 +320,9 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 // the 512-thread kernel has per lane) the allocator spills a third of it to scratch, and a scratch reload inside a BCR
 // level costs more than the LDS read it replaced (measured: 160 ms against 140 ms per step on the map100 set); 60 doubles
 // leave the hot loop spill-free.  The other 33 sit in LDS (Shm::fx): read by one lane, once per sweep.
+#if !defined(CSDO_SINV_LDS)
+#define CSDO_SINV_LDS 1   // 1: the pivot inverse of a node (21 doubles, read once per iteration in the w pass) sits in LDS; 0: in the workspace
+#endif
 #if !defined(CSDO_ER_REG)
 #define CSDO_ER_REG 24   // measured again after the plane-pass fix (map100 set, ms per step): 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
 #endif
@@ -288,13 +341,18 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
   unsigned act;             // rows that exist at this t
   int ncols;                // 6, or 4 at t = Nt-1
 };
-struct SolvRegs {           // solver lane of timestep t: BCR node t, both couplings in registers during an ADMM block
+struct SolvRegs {           // solver lane of timestep t during an ADMM block
   double b[6];              // rhs -> BCR work vector -> x_tilde
-  double el[36];            // F_l = Sinv E_l: coupling to the left neighbour at this node's elimination level
+  // Long-horizon modes (2, 3): BCR node t with both couplings, F_l = Sinv E_l in el (modes 2, 3 fetch F_r where they use it).
+  // Pair-split modes (0, 1): the two 6x6 blocks this LANE multiplies with, one per level it works at (see "pair-split solve"
+  // in dsqp_program_impl.h): el = the block of level 1, er = the first ER_REG entries of the block of the lane's level >= 2
+  // (the rest: LDS, Shm::fx; mode 1: the workspace)
+  double el[36];
   int ts0, ts1;             // plane range of this timestep (CSR offsets), for the rhs assembly
-  double er[ER_REG];        // F_r = E_r Sinv: coupling to the right neighbour, first ER_REG entries (the rest: LDS, Shm::fx;
-};                          //                                                              MODE 3: all from the workspace)                          // (the pivot inverse, only needed in the forward sweep, sits in LDS: with it the lane would
-                            //  hold 198 of its 256 registers and the compiler spills a third of the factor to scratch)
+  double er[ER_REG];
+  double v[6], o[6];        // pair-split: operand and product of the level at hand (short-lived; lane state only for the lane-serial build)
+  unsigned fl;              // pair-split: what the lane does at which level (XF_* below)
+};
 typedef RowRegs LaneState;  // the row lane is the "home" of a timestep
 
 // Per-agent workspace in HBM (L2-resident), SoA [slot][stride]: the master copy of every per-lane quantity.
@@ -323,7 +381,7 @@ enum WsSlot {
 // lane-major leading dimensions (doubles per lane) of the LDS arrays.  All are 2 * odd: 16-byte aligned lanes, and the
 // ds_read_b128 / ds_write_b128 of 16 consecutive lanes (also of lanes a power of two apart) fall into 16 different
 // 4-bank groups - conflict free.  (12 doubles, the former reduction stride, is 2-way conflicting.)
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + 21 + 1) / 2) | 1),
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + (CSDO_SINV_LDS ? 21 : 0) + 1) / 2) | 1),
               // the block's per-timestep arrays (vec .. fx) double as the factorisation's exchange columns, 78 fields x stride
               LD_block = (24 + LD_lohi + LD_fx) > 78 ? (24 + LD_lohi + LD_fx) : 78,
               LD_stash = 38, LD_tinv = 38, LD_prow = 10;

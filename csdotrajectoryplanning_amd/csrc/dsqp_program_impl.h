@@ -12,13 +12,13 @@ namespace csdo {
 // the access is `global_load v, v_lane, s[base]` - no per-field 64-bit address in vector registers (the compiler
 // otherwise hoists those out of the loops and spills them: a scratch reload in front of every workspace access)
 #define SX(k, t) (sh.facX + (size_t)(k) * (size_t)csdo_opaque_s(sh.stride))[(unsigned)(t)]
-#define FE(k, t) (sh.facE + (k))[(unsigned)(t) * 72u]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
+#define FE(k, t) (sh.facE + (k))[(unsigned)(t) * (unsigned)FAC_E_DOUBLES]   // lane-major: one lane register + immediate offsets (SoA and tiles measured slower)
 // F_r of node t: the solver lane's registers for the first ER_REG entries, LDS for the rest and for the pivot inverse;
 // everything from the workspace for long horizons
 // (MODE 2: the lean modes' layout - nothing of the factor in registers - with all of F_r in LDS, 36 doubles per timestep)
 #define FX2(k, t) sh.fx[(t) * 36 + (k)]
 #define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : (MODE == 2 ? FX2(k, t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t)))))
-#define SINV(k, t) (MODE >= 1 ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
+#define SINV(k, t) ((MODE >= 1 || !CSDO_SINV_LDS) ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 // set-up stage scratch, field-major over the ADMM block's exchange arrays (see "assemble the QP")
 #define SU(k, t) sh.vec[(size_t)(k) * (size_t)csdo_opaque_s(sh.stride) + (unsigned)(t)]
 // (the stride passes through an empty asm at every use: the per-slot base addresses - some sixty 64-bit scalars - are then formed
@@ -133,6 +133,13 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
 // =========================================================================================================
 #define FA(k, t) SX(78 + (k), t)
 #define FR(k, t) FE(36 + (k), t)
+// Pair-split modes: where the solve wants the factor of node t (see "pair-split solve" below).  F_l(t), transposed (entry [c][r]
+// at c * 6 + r), goes to the lane that multiplies with it - an odd node's to lane t - 1 (its level-1 block, FE 0..35), an even
+// node's to its own lane (the block of its level, FE 72..107); F_r(t), as it is, to the other lane of the pair: lane t (odd node,
+// level-1 block) or lane t + 1 (even node).  A node without a right neighbour leaves there the second half of F_l instead
+// (columns 3..5, the rest zero): its backward step is two half-sums over F_l, and the partner lane forms the second one.
+#define PF_L(idx, t) sh.facE[(unsigned)((t) - ((t) & 1)) * (unsigned)FAC_E_DOUBLES + (unsigned)((((t) & 1) ? 0 : 72) + (idx))]
+#define PF_R(idx, t) sh.facE[(unsigned)((t) + 1 - ((t) & 1)) * (unsigned)FAC_E_DOUBLES + (unsigned)((((t) & 1) ? 0 : 72) + (idx))]
 #define ROW(r, f) (rows + (int64_t)(f) * rcap)[(unsigned)(r)]
 #if defined(CSDO_PROFILE_PHASES)
 struct FactorProf {   // diagnostic build: the caller's phase timers (slots 16..18: assembly, levels, tail inversion)
@@ -286,7 +293,8 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 });
                 CSDO_FOR(r, 6, {
                   XC(r * 6 + c, t) = tc[r];
-                  FE(r * 6 + c, t) = tc[r];
+                  PF_L(c * 6 + r, t) = tc[r];
+                  if (!has_r) PF_R(c * 6 + r, t) = (c >= 3) ? tc[r] : 0.0;
                 });
                 CSDO_FOR(a_, 6, {            // column c of U_l = Rl' T (lower triangle)
                   double a = 0.0;
@@ -360,7 +368,12 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 double a = 0.0;
                 CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rl[k * 6 + c], a); });
                 STASH(r * 6 + c) = a;
-                FE(r * 6 + c, t) = a;      // F_l = Sinv * E_l, what the solve uses
+                if constexpr (MODE < 2) {  // F_l = Sinv * E_l, what the solve uses (pair-split modes: where its lane reads it)
+                  PF_L(c * 6 + r, t) = a;
+                  if (!has_r) PF_R(c * 6 + r, t) = (c >= 3) ? a : 0.0;
+                } else {
+                  FE(r * 6 + c, t) = a;
+                }
               });
             });
             CSDO_STAGE();
@@ -410,7 +423,8 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
               });
             });
             CSDO_STAGE();
-            CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = STASH(r * 6 + c); }); });
+            if constexpr (MODE < 2) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = STASH(r * 6 + c); }); });
+            else CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = STASH(r * 6 + c); }); });
           }
 #undef STASH
 #undef PUT_UL
@@ -477,7 +491,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     CSDO_FPHASE(19);
     CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements and take the coupling to their new right neighbour
       if constexpr (MODE == 0) {   // (beside them, the eliminated nodes move F_r = V' from their LDS column to its place)
-        if ((t & m2) == h && (t + h) < Nt) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = XC(r * 6 + c, t); }); });
+        if ((t & m2) == h && (t + h) < Nt) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = XC(r * 6 + c, t); }); });
       }
       if ((t & m2) == 0) {
         double A[21];
@@ -593,14 +607,18 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       CSDO_SYNC();
     }
   }
-  CSDO_TLANES(t) {
-    if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });
+  if constexpr (MODE >= 2) {   // (node 0 is never eliminated: its lane's blocks are loaded with the others and never used)
+    CSDO_TLANES(t) {
+      if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });
+    }
   }
   CSDO_SYNC();
   CSDO_FPHASE(18);
 }
 #undef FA
 #undef FR
+#undef PF_L
+#undef PF_R
 #undef XC
 #undef ROW
 
@@ -638,6 +656,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   int h_tail = 1;                       // BCR levels run for h < h_tail; nodes k * h_tail form the dense tail
   while ((Nt + h_tail - 1) / h_tail > TAIL_NODES) h_tail <<= 1;
   const int R_tail = (Nt + h_tail - 1) / h_tail, n_tail = 6 * R_tail;
+  int lg_tail = 0;
+  while ((1 << lg_tail) < h_tail) ++lg_tail;
+  (void)lg_tail;
+  const int NtE = (Nt + 1) & ~1;        // lanes of the pair-split solve: the horizon rounded up to whole pairs
+  (void)NtE;
 #if defined(CSDO_PROFILE_PHASES)
   long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 16..23: factor sub-phases
   long long prof_last = (long long)__builtin_amdgcn_s_memtime();
@@ -646,11 +669,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #define CSDO_SUB_RESET() do { if (threadIdx.x == 0) sub_last = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define CSDO_SUB(k) do { if (threadIdx.x == 0) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); sub_acc[k] += n_ - sub_last; sub_last = n_; } } while (0)
   long long lvl_fwd = 0, lvl_bwd = 0;  // solver lane t == h: cycles inside its own elimination block
+  // pair-split solve: a stopwatch every wave keeps for itself (scalar registers); the first and the third solver wave report
+  long long xs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xs_last = 0;
+#define CSDO_XT_RESET() xs_last = (long long)__builtin_amdgcn_s_memtime()
+#define CSDO_XT(k) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); xs_acc[k] += n_ - xs_last; xs_last = n_; } while (0)
 #define CSDO_LVL_BEGIN() const long long lvl_t0 = (long long)__builtin_amdgcn_s_memtime()
 #define CSDO_LVL_END(acc) acc += (long long)__builtin_amdgcn_s_memtime() - lvl_t0
 #else
 #define CSDO_LVL_BEGIN() ((void)0)
 #define CSDO_LVL_END(acc) ((void)0)
+#define CSDO_XT_RESET() ((void)0)
+#define CSDO_XT(k) ((void)0)
 #define CSDO_SUB_RESET() ((void)0)
 #define CSDO_SUB(k) ((void)0)
 #endif
@@ -1060,7 +1089,308 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // ============================================================== BCR solve on the solver lanes.
     // In: rhs of node t in V.b (assembled by the solver lane).  Out: x_tilde in V.b and sh.vec[t].
     // Coupling blocks and pivot inverses come from registers: the only LDS traffic is the 6-vectors.
-    auto solve = [&]() __attribute__((always_inline)) {
+    // ============================================================== pair-split solve (residency modes 0 and 1)
+    // A level of the reduction is, per eliminated node, two 6x6 products of the node's rhs (forward: pl = F_l' b for the left
+    // neighbour, pr = F_r b for the right one; backward: x = (w - F_l x_left) + (0 - F_r' x_right)) - 72 multiply-adds deep on
+    // the node's lane, while at least every other lane of its wave has nothing to do.  Here the two products sit on the two
+    // lanes of the node's PAIR (2j, 2j + 1), one block each:
+    //   level 1 (odd nodes t):     lane t - 1 holds F_l(t)' and forms pl(t) - which it consumes itself -, lane t holds F_r(t);
+    //   levels h >= 2 (even nodes): lane t holds F_l(t)', lane t + 1 (an odd lane: eliminated at level 1, idle since) holds F_r(t).
+    // A lane works at level 1 and at ONE further level, so it keeps two blocks (SolvRegs::el, er + Shm::fx).  The rhs reaches the
+    // partner lane by a DPP move (quad_perm inside the pair), every element is the same chain of multiply-adds as in the
+    // one-lane form (half-sums of three in the forward sweep, chains of six from w and from 0 in the backward one) - bit for bit.
+    // Partners of an elimination are h <= 32 lanes apart and, but for one case, in the same WAVE: the levels exchange their
+    // partials through LDS without workgroup barriers (a wave's LDS instructions complete in order; level 1 by DPP).  The one
+    // case is the first lane of a wave (a multiple of 64: always a tail node), whose LEFT partials come from the last lanes of the
+    // wave in front of it: that wave adds them up behind its last level and hands the sum over beside the gathered tail rhs
+    // (see the gather); the tail product subtracts it.  Backward, a wave only ever needs x of its own nodes and of the next
+    // wave's first node - a tail node, known since the tail product.
+    // Barriers per solve: 3 (levels + gather | tail product beside the w pass | backward) instead of 2 log2(Nt / 6) + 2.
+    // Measured: fixed-work iteration 10.45 -> 9.3 us on one instance alone, 2.5 % under a full batch.
+    constexpr unsigned XF_ABS = 1u, XF_ABSR = 1u << 6, XF_WR = 1u << 12, XF_OWN = 1u << 18, XF_NR = 1u << 24;
+#define A2_LDS(k, tt) (MODE == 1 ? FE(72 + ER_REG + (k), tt) : SH(fx, (k), tt))   /* the block's entries beyond ER_REG */
+    auto solve_pair = [&](auto) __attribute__((always_inline)) {   // (generic: only instantiated for the modes that call it)
+      CSDO_MARK("solve_begin");
+      CSDO_PHASE(7);
+#if defined(CSDO_ABL_NOSOLVE)
+      CSDO_SYNC();
+      return;
+#endif
+      CSDO_XT(0);   // (since the barrier behind the update: rhs assembly)
+#if defined(CSDO_ABL_XNOFWD)
+      if (false) {
+#else
+      if (h_tail > 1) {
+#endif
+        // (the one-trip loops around the two level-1 steps: the register allocator weighs a value by the loop depth of its uses,
+        //  and outside any loop of the iteration the level-1 block would be what it spills)
+        for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
+        CSDO_XLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
+          CSDO_FOR(k, 6, { V.v[k] = CSDO_XGET(CSDO_DPP_PAIR_ODD, b, k); });   // both lanes of a pair: the odd node's rhs
+        CSDO_XSTEP(t)
+          {
+            double qa[6] = {0, 0, 0, 0, 0, 0}, qb[6] = {0, 0, 0, 0, 0, 0};
+            CSDO_FOR(k, 3, {
+              CSDO_FOR(a, 6, {
+                qa[a] = fma(V.el[a * 6 + k], V.v[k], qa[a]);
+                qb[a] = fma(V.el[a * 6 + k + 3], V.v[k + 3], qb[a]);
+              });
+            });
+            CSDO_FOR(a, 6, { V.o[a] = qa[a] + qb[a]; });   // even lane t: pl(t + 1); odd lane t: pr(t)
+          }
+          if (V.fl & XF_WR) {   // what crosses a wave boundary waits in LDS
+            if (t & 1) CSDO_FOR(k, 6, { SH(pr, k, t) = V.o[k]; });
+            else CSDO_FOR(k, 6, { SH(pl, k, t + 1) = V.o[k]; });
+          }
+        CSDO_XSTEP(t)
+          double left[6];
+          CSDO_FOR(k, 6, { left[k] = CSDO_XGET(CSDO_DPP_PREV, o, k); });
+          if (V.fl & XF_ABS) CSDO_FOR(k, 6, { V.b[k] -= left[k]; });
+          if (V.fl & XF_ABSR) CSDO_FOR(k, 6, { V.b[k] -= V.o[k]; });
+        }
+        CSDO_XT(1);   // forward level 1
+        int lev = 1;
+        for (int h = 2; h < h_tail; h <<= 1, ++lev) {
+          CSDO_XLANES(t) {
+            SolvRegs& V = CSDO_SS(t);
+            CSDO_FOR(k, 6, { V.v[k] = CSDO_XGET(CSDO_DPP_PAIR_EVEN, b, k); });   // both lanes of a pair: the even node's rhs
+          CSDO_XSTEP(t)
+            {
+              const int tl = t < NtE ? t : NtE - 1;
+              double m2x[FX_ER > 0 ? FX_ER : 1];
+              CSDO_FOR(k, FX_ER, { m2x[k] = A2_LDS(k, tl); });
+              double qa[6] = {0, 0, 0, 0, 0, 0}, qb[6] = {0, 0, 0, 0, 0, 0};
+#define A2(kk) ((kk) < ER_REG ? V.er[(kk) < ER_REG ? (kk) : 0] : m2x[(kk) >= ER_REG ? (kk) - ER_REG : 0])
+              CSDO_FOR(k, 3, {
+                CSDO_FOR(a, 6, {
+                  qa[a] = fma(A2(a * 6 + k), V.v[k], qa[a]);
+                  qb[a] = fma(A2(a * 6 + k + 3), V.v[k + 3], qb[a]);
+                });
+              });
+              CSDO_FOR(a, 6, { V.o[a] = qa[a] + qb[a]; });   // even lane t: pl(t); odd lane t: pr(t - 1)
+            }
+            // level 2 hands its partials over in registers (the helper of node s - 2 is lane s - 1: wave_shr:1; node s + 2 is two
+            // lanes up in the same row of 16: row_shl:2); only the one that leaves the wave goes to LDS (for the hand-over sum)
+            if ((V.fl & (XF_WR << lev)) && (h != 2 || (t & 63) == 63)) {
+              if (t & 1) CSDO_FOR(k, 6, { SH(pr, k, t - 1) = V.o[k]; });
+              else CSDO_FOR(k, 6, { SH(pl, k, t) = V.o[k]; });
+            }
+          }
+          if (h == 2) {
+            CSDO_XLANES(t) {
+              SolvRegs& V = CSDO_SS(t);
+              double left[6], right[6];
+              CSDO_FOR(k, 6, { left[k] = CSDO_XGET(CSDO_DPP_PREV, o, k); });
+              CSDO_FOR(k, 6, { right[k] = CSDO_XGET(CSDO_DPP_ROW_PLUS2, o, k); });
+              if (V.fl & (XF_ABS << 1)) CSDO_FOR(k, 6, { V.b[k] -= left[k]; });
+              if (V.fl & (XF_ABSR << 1)) CSDO_FOR(k, 6, { V.b[k] -= right[k]; });
+            }
+          } else {
+            CSDO_XLANES(t) {
+              SolvRegs& V = CSDO_SS(t);
+            CSDO_XSTEP_LDS(t)
+              if (V.fl & (XF_ABS << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - h); });
+              if (V.fl & (XF_ABSR << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + h); });
+            }
+          }
+        }
+      }
+      // ---- tail nodes gather their rhs.  The first node of a wave (a multiple of 64: a tail node) takes its LEFT partials from the
+      // wave in front of it; that wave sums them up behind its last level - six lanes, one component each, in the order of the
+      // levels - and leaves the sum beside the gathered rhs (second half of tvec; zero for every other tail node), the tail product
+      // subtracts it.  (With the left partials absorbed one by one in level order, as the one-lane form does, the node's wave
+      // has to wait for a barrier in front of the gather and catch up behind it: 2.7 k cycles of every iteration as a loop, 1.1 us
+      // of 10.5 even with six lanes and all partials in flight.  The order of those few subtractions is the only thing this
+      // form changes in the arithmetic.)
+      CSDO_SLANES(t) {
+        SolvRegs& V = CSDO_SS(t);
+        if ((t & (h_tail - 1)) == 0) {
+          const int kn = t >> lg_tail;
+          CSDO_FOR(k, 6, { sh.tvec[6 * kn + k] = V.b[k]; });
+        }
+      }
+      if (h_tail > 1) {
+#if defined(CSDO_LANE_MODE_DEVICE)
+        if constexpr (ROLE != ROLE_ROW) csdo_wave_sync();   // (this wave's own partials of the last level, through LDS)
+#endif
+        CSDO_HANDOVER_LANES(s, q) {
+          double part[6];
+          CSDO_FOR(l6, 6, {   // (levels 1, 2, 4, ... 32: one that does not exist reads some valid slot and is skipped below)
+            constexpr int h = 1 << l6;
+            part[l6] = sh.pr[(s - (h < h_tail ? h : 1)) * LD_pr + q];
+          });
+          double acc = part[0];
+          CSDO_FOR(l6, 5, {
+            constexpr int h = 2 << l6;
+            if (h < h_tail) acc += part[l6 + 1];
+          });
+          sh.tvec[TAIL_N + 6 * (s >> lg_tail) + q] = acc;
+        }
+      }
+      CSDO_XT(2);   // forward levels >= 2
+      CSDO_PHASE(13);
+      CSDO_SYNC();
+      CSDO_XT(3);   // wait at the barrier in front of the tail
+      CSDO_PHASE(22);
+#if defined(CSDO_LANE_MODE_DEVICE)
+      // The product of the explicit tail inverse with the gathered rhs runs on the ROW waves (see the long-horizon form below)
+#if defined(CSDO_ABL_XNOTAILP)
+      if constexpr (false) {
+#else
+      if constexpr (ROLE == ROLE_ROW) {
+#endif
+        const int x = (int)threadIdx.x, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
+        if (x < 128) {
+          double a0 = 0.0, a1 = 0.0;
+          if (wl < 63 && r < n_tail) {
+            double tr0[6], tr1[6], tb0[6], tb1[6];
+            CSDO_FOR(j, 6, {
+              tr0[j] = SH(tinv, 6 * j + p2, r);
+              tr1[j] = SH(tinv, 6 * j + p2 + 1, r);
+              tb0[j] = sh.tvec[6 * j + p2] - sh.tvec[TAIL_N + 6 * j + p2];
+              tb1[j] = sh.tvec[6 * j + p2 + 1] - sh.tvec[TAIL_N + 6 * j + p2 + 1];
+            });
+            CSDO_FOR(j, 6, {
+              a0 = fma(tr0[j], tb0[j], a0);
+              a1 = fma(tr1[j], tb1[j], a1);
+            });
+          }
+          const double s01 = a0 + a1;
+          const double up1 = wave_next(s01), up2 = wave_next(up1);
+          const double s0123 = s01 + up1;
+          const double tot = s0123 + up2;
+          if (wl < 63 && r < n_tail && p2 == 0) {
+            const int kn = r / 6, i = r - 6 * kn;
+            sh.vec[(kn * h_tail) * LD_vec + i] = tot;
+          }
+        }
+      }
+      if constexpr (ROLE == ROLE_BOTH)
+#endif
+      CSDO_TLANES_TOP(t) {
+        double a4[6] = {0, 0, 0, 0, 0, 0};
+        CSDO_FOR(q, 4, {
+          double tr[TAIL_N / 4], tb[TAIL_N / 4];
+          CSDO_FOR(c, TAIL_N / 4, {
+            tr[c] = SH(tinv, q * (TAIL_N / 4) + c, t);
+            tb[c] = sh.tvec[q * (TAIL_N / 4) + c] - sh.tvec[TAIL_N + q * (TAIL_N / 4) + c];
+          });
+          CSDO_FOR(c, TAIL_N / 4, { a4[(q * (TAIL_N / 4) + c) % 6] = fma(tr[c], tb[c], a4[(q * (TAIL_N / 4) + c) % 6]); });
+          CSDO_STAGE();
+        });
+        const int kn = t / 6, i = t - 6 * kn;
+        sh.vec[(kn * h_tail) * LD_vec + i] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + (a4[4] + a4[5]);
+      }
+      // beside the tail product: w = Sinv b, the start of every eliminated node's backward chain.  An even node's on its own
+      // lane; an odd node's on the even lane to its left, which forms that node's F_l half in the backward sweep.  The odd
+      // lanes only form second halves, which start from 0.
+      auto sinv_times = [&](const int node, const double (&bb)[6], double (&w6)[6]) __attribute__((always_inline)) {
+        const int nd = csdo_keep(node);   // (the LDS address formed here: hoisted out of the iterations it is spilled)
+        CSDO_FOR(half, 2, {
+          double sv[3][6];
+          CSDO_FOR(r3, 3, {
+            CSDO_FOR(c, 6, { sv[r3][c] = SINV(sym(3 * half + r3, c), nd); });
+          });
+          CSDO_FOR(r3, 3, {
+            const double s01 = fma(sv[r3][1], bb[1], sv[r3][0] * bb[0]);
+            const double s23 = fma(sv[r3][3], bb[3], sv[r3][2] * bb[2]);
+            const double s45 = fma(sv[r3][5], bb[5], sv[r3][4] * bb[4]);
+            w6[3 * half + r3] = (s01 + s23) + s45;
+          });
+          CSDO_STAGE();
+        });
+      };
+#if defined(CSDO_ABL_XNOW)
+      if (false) {
+#else
+      if (h_tail > 1) {
+#endif
+        CSDO_XLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
+          // every eliminated node forms its own w on its own lane (one product per lane, in the shadow of the tail product on
+          // the row waves); an odd node's w then moves to the even lane of its pair, where its backward chain starts
+          if (t < Nt && ((t & 1) || (t & (h_tail - 1)) != 0)) {
+            double w6[6];
+            sinv_times(t, V.b, w6);
+            CSDO_FOR(k, 6, { V.o[k] = w6[k]; });
+          }
+        CSDO_XSTEP(t)
+          double w1[6];
+          CSDO_FOR(k, 6, { w1[k] = CSDO_XGET(CSDO_DPP_PAIR_ODD, o, k); });   // even lane: w of node t + 1
+          // the odd lanes only form second half-sums, which start from 0; an even node's chain starts from its w (tail nodes keep
+          // their rhs, which is not used again); w of the odd node waits in the even lane's own slot of the forward sweep's
+          // partials, idle by now, for the last backward level (six doubles less in registers across the sweep)
+          if (t & 1) {
+            CSDO_FOR(k, 6, { V.b[k] = 0.0; });
+          } else {
+            if (t < Nt && (t & (h_tail - 1)) != 0) CSDO_FOR(k, 6, { V.b[k] = V.o[k]; });
+            if ((t + 1) < Nt) CSDO_FOR(k, 6, { SH(pr, k, t) = w1[k]; });
+          }
+        }
+      }
+      CSDO_XT(5);   // w pass
+      CSDO_SYNC();
+      CSDO_XT(6);   // wait for the tail product
+      CSDO_PHASE(8);
+#if defined(CSDO_ABL_XNOBWD)
+      if (false) {
+#else
+      if (h_tail > 1) {
+#endif
+        int lev = 0;
+        for (int h = 1; 2 * h < h_tail; h <<= 1) ++lev;
+        for (int h = h_tail >> 1; h >= 2; h >>= 1, --lev) {
+          CSDO_XLANES(t) {
+            SolvRegs& V = CSDO_SS(t);
+            const int tl = t < NtE ? t : NtE - 1;
+            double m2x[FX_ER > 0 ? FX_ER : 1];
+            CSDO_FOR(k, FX_ER, { m2x[k] = A2_LDS(k, tl); });
+            // the node's lane takes x of the left neighbour, its partner x of the right one - or, for a node without one, of
+            // the left one again (second half of F_l, see the factorisation); lanes not at work read any valid slot
+            const int n = t & ~1;
+            int src = (t & 1) ? (((n + h) < Nt) ? n + h : n - h) : t - h;
+            src = src < 0 ? 0 : (src >= NtE ? NtE - 1 : src);
+            CSDO_FOR(k, 6, { V.v[k] = SH(vec, k, src); });
+            if (V.fl & (XF_NR << lev)) CSDO_FOR(k, 3, { V.v[3 + k] = 0.0; });
+            CSDO_FOR(r, 6, { V.o[r] = V.b[r]; });
+            CSDO_FOR(c, 6, {
+              CSDO_FOR(r, 6, { V.o[r] = fma(-A2(c * 6 + r), V.v[c], V.o[r]); });
+            });
+          CSDO_XSTEP(t)
+            double ub[6];
+            CSDO_FOR(k, 6, { ub[k] = CSDO_XGET(CSDO_DPP_PAIR_SWAP, o, k); });
+            if (V.fl & (XF_OWN << lev)) CSDO_FOR(k, 6, { SH(vec, k, t) = V.o[k] + ub[k]; });
+          CSDO_XSTEP_LDS(t)
+            (void)V;
+          }
+        }
+        for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
+        CSDO_XLANES(t) {   // level 1: x of the odd nodes, summed and stored by the even lane of the pair
+          SolvRegs& V = CSDO_SS(t);
+          int src = (t & 1) ? (((t + 1) < Nt) ? t + 1 : t - 1) : t;
+          src = src >= NtE ? NtE - 1 : src;
+          CSDO_FOR(k, 6, { V.v[k] = SH(vec, k, src); });
+          if (V.fl & XF_NR) CSDO_FOR(k, 3, { V.v[3 + k] = 0.0; });
+          if (V.fl & XF_OWN) CSDO_FOR(k, 6, { V.b[k] = SH(pr, k, t); });   // even lane: w of the odd node; odd lanes start from their 0
+          CSDO_FOR(r, 6, { V.o[r] = V.b[r]; });
+          CSDO_FOR(c, 6, {
+            CSDO_FOR(r, 6, { V.o[r] = fma(-V.el[c * 6 + r], V.v[c], V.o[r]); });
+          });
+        CSDO_XSTEP(t)
+          double ub[6];
+          CSDO_FOR(k, 6, { ub[k] = CSDO_XGET(CSDO_DPP_PAIR_ODD, o, k); });
+          if (V.fl & XF_OWN) CSDO_FOR(k, 6, { SH(vec, k, t + 1) = V.o[k] + ub[k]; });
+        }
+      }
+      CSDO_XT(7);   // backward sweep
+      CSDO_PHASE(14);
+      CSDO_SYNC();
+      CSDO_PHASE(8);
+#undef A2
+    };
+
+    auto solve_lds = [&](auto) __attribute__((always_inline)) {
       CSDO_MARK("solve_begin");
       CSDO_PHASE(7);
 #if defined(CSDO_ABL_NOSOLVE)
@@ -1268,6 +1598,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_SYNC();
         CSDO_PHASE(8);
       }
+    };
+
+    auto solve = [&]() __attribute__((always_inline)) {
+      if constexpr (MODE < 2) solve_pair(0);
+      else solve_lds(0);
     };
 
     // (one site for the factorisation, at the top of the block loop: every inlined copy of a large cold piece takes part in
@@ -1674,19 +2009,65 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         publish_rhs(S, t);
       }
-      CSDO_SLANES(t) {  // load the solver-lane cache: 60 doubles of the node's factor in registers, 33 in LDS
-        SolvRegs& V = CSDO_SS(t);
-        CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
-        if constexpr (MODE == 2) CSDO_FOR(k, 36, { FX2(k, t) = FE(36 + k, t); });
-        if constexpr (MODE < 2) {
-          CSDO_FOR(k, ER_REG, { V.er[k] = FE(36 + k, t); });
-          if constexpr (MODE == 0) {
-            CSDO_FOR(k, FX_ER, { SH(fx, k, t) = FE(36 + ER_REG + k, t); });
-            CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
-          }
+      if constexpr (MODE >= 2) {
+        CSDO_SLANES(t) {  // load the solver-lane cache: F_l of the node in registers
+          SolvRegs& V = CSDO_SS(t);
+          CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
+          if constexpr (MODE == 2) CSDO_FOR(k, 36, { FX2(k, t) = FE(36 + k, t); });
+          V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
+          V.ts1 = csdo_keep(tstart[t + 1]);
         }
-        V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
-        V.ts1 = csdo_keep(tstart[t + 1]);
+      } else {
+        // pair-split solve: the LANE's two blocks (as the factorisation left them for it), 36 + ER_REG doubles in registers, the
+        // rest of the second block and the node's pivot inverse in LDS; what the lane does at which level as bit masks
+        CSDO_XLANES(t) {
+          SolvRegs& V = CSDO_SS(t);
+          const int tl = t < NtE ? t : NtE - 1;   // (threads beyond the horizon take part in the wave's moves: any valid address)
+          CSDO_FOR(k, 36, { V.el[k] = FE(k, tl); });
+          CSDO_FOR(k, ER_REG, { V.er[k] = FE(72 + k, tl); });
+          if constexpr (MODE == 0) {
+            if (t < NtE) {
+              CSDO_FOR(k, FX_ER, { SH(fx, k, t) = FE(72 + ER_REG + k, t); });
+              if constexpr (CSDO_SINV_LDS != 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
+            }
+          }
+          V.ts0 = V.ts1 = 0;
+          if (t < Nt) {
+            V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
+            V.ts1 = csdo_keep(tstart[t + 1]);
+          }
+          unsigned fl = 0;
+          if (t < NtE) {
+            const bool odd = (t & 1) != 0;
+            int lev = 0;
+            for (int h = 1; h < h_tail; h <<= 1, ++lev) {
+              const int m2 = 2 * h - 1;
+              if (!odd && t < Nt && (t & m2) == 0) {   // takes the level's partials: the right one always, the left one unless it
+                if ((t & 63) != 0) fl |= XF_ABS << lev;   // comes from the wave in front (that wave hands the sum of them over, below)
+                if ((t + h) < Nt) fl |= XF_ABSR << lev;
+              }
+              if (lev == 0) {
+                // in-wave partials of level 1 travel by DPP; LDS only holds what the next wave's / this wave's first node takes later
+                if (odd && (t & 63) == 63 && (t + 1) < Nt) fl |= XF_WR;
+                if (!odd && (t + 1) < Nt) {
+                  fl |= XF_OWN;
+                  if ((t + 2) >= Nt) fl |= XF_NR;
+                }
+              } else {
+                const int n = t & ~1;            // the node this pair works for at its level
+                if ((n & m2) == h && n < Nt) {
+                  if (!odd) {
+                    fl |= (XF_WR | XF_OWN) << lev;
+                    if ((n + h) >= Nt) fl |= XF_NR << lev;
+                  } else if ((n + h) < Nt) {
+                    fl |= XF_WR << lev;
+                  }
+                }
+              }
+            }
+          }
+          V.fl = fl;
+        }
       }
       if (rows_lds) {   // the inter-vehicle rows' duals, slacks and timesteps live in LDS for the whole QP (nothing else uses
         CSDO_STHREADS(l, nthr) {   // that part of it): staged in front of the QP's first block only
@@ -1712,6 +2093,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_SYNC();
       CSDO_SUB(5);
+      CSDO_XT_RESET();
       auto iteration = [&](auto keep_c) __attribute__((always_inline)) {
         constexpr bool keep_dy = decltype(keep_c)::value;   // only the last iteration of a block records delta_y
         // ---- rhs of the reduced system: the solver lane adds the kinematic share of t-1 and its planes' shares to what
@@ -1818,6 +2200,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
         }
         CSDO_SYNC();
+        CSDO_XT_RESET();
       };
       first_block = false;
       while (iter < stop - 1) {
@@ -2007,6 +2390,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       while ((1 << lv) < ts) ++lv;
       B.prof[(int64_t)agent * 48 + 16 + lv] = lvl_fwd;
       B.prof[(int64_t)agent * 48 + 32 + lv] = lvl_bwd;
+    }
+    if constexpr (MODE < 2) {
+      if (B.prof && (ts == 1 || ts == 129)) for (int k = 0; k < 8; ++k) B.prof[(int64_t)agent * 48 + (ts == 1 ? 16 : 32) + k] = xs_acc[k];
     }
   }
 #endif

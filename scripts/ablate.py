@@ -15,5 +15,6 @@ h = DsqpHandle(0); h.upload([w]); h.run(); ks = min(h.run() for _ in range(3)); 
 it = max(int(s.admm_iters.max()), 1)
 print('%-16s kernel %.2f ms  iters/agent %d  -> %.2f us per iteration' % (V, ks * 1e3, it, ks * 1e6 / it))
 """
-for v in ["FIXED", "FIXED_NOSOLVE", "FIXED_NOLEVELWORK", "FIXED_NOBWDWORK"]:
+VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["FIXED", "FIXED_NOSOLVE", "FIXED_NOLEVELWORK", "FIXED_NOBWDWORK"]
+for v in VARIANTS:
     subprocess.run([sys.executable, "-c", CODE, v])

@@ -52,3 +52,7 @@ for label, sel in (("all agents", it >= 0), ("short agents (< 1000 iterations)",
     print("   cycles inside a level's elimination block (lane 2^lv), fwd: " +
           " ".join("%.0f" % ((fw[:, lv][has[:, lv]] / itv[has[:, lv], 0]).mean() if has[:, lv].any() else 0) for lv in range(6)) +
           "  bwd: " + " ".join("%.0f" % ((bw[:, lv][has[:, lv]] / itv[has[:, lv], 0]).mean() if has[:, lv].any() else 0) for lv in range(6)))
+    xs = ph[sel][:, 16:24].astype(float); xs2 = ph[sel][:, 32:40].astype(float)
+    lab = ["rhs assembly", "fwd level 1", "fwd levels >= 2 + gather + hand-over", "wait at barrier", "-", "w pass", "wait for tail product", "backward sweep"]
+    print("   pair-split solve, solver wave 0 (cycles per ADMM iteration): " + "  ".join("%s %.0f" % (lab[k], xs[:, k].sum() / n_it) for k in range(8)) + "  | sum %.0f" % (xs.sum() / n_it))
+    print("   pair-split solve, solver wave 2 (cycles per ADMM iteration): " + "  ".join("%s %.0f" % (lab[k], xs2[:, k].sum() / n_it) for k in range(8)) + "  | sum %.0f" % (xs2.sum() / n_it))

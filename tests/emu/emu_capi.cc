@@ -100,7 +100,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;
     sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
     std::vector<RowRegs> lanes_r(ad.Nt);
-    std::vector<SolvRegs> lanes_s(std::max<int>(ad.Nt, TAIL_N));
+    std::vector<SolvRegs> lanes_s(std::max<int>(ad.Nt + 2, TAIL_N));   // (+ the partner lane of a last, even node)
     ProgramOut po{};
     if (mode == 0) agent_program<ROLE_BOTH, 0>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 1) agent_program<ROLE_BOTH, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);

@@ -3,12 +3,17 @@
 #   usage: collect_round.sh <tag>
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r02}
-python scripts/summarize_profiles.py gpurun_out $TAG map100 > /dev/null 2>&1
-python scripts/summarize_profiles.py gpurun_out $TAG map50 > /dev/null 2>&1
-for w in map100 map50 synth1024; do tail -1 gpurun_out/$TAG/bench_$w.json > profiles/${TAG}_bench_$w.json; done
-cp gpurun_out/$TAG/parity_map100.json profiles/${TAG}_parity_map100.json
-cp gpurun_out/$TAG/parity_map50.json profiles/${TAG}_parity_map50.json
+TAG=${1:-r04}
+for w in map100 map50 synth1024 room50 agents100; do
+  python scripts/summarize_profiles.py gpurun_out $TAG $w > /dev/null 2>&1
+  [ -f gpurun_out/$TAG/bench_$w.json ] && tail -1 gpurun_out/$TAG/bench_$w.json > profiles/${TAG}_bench_$w.json
+done
+[ -f gpurun_out/$TAG/bench_map100_force_dist.json ] && tail -1 gpurun_out/$TAG/bench_map100_force_dist.json > profiles/${TAG}_bench_map100_force_dist.json
+[ -f gpurun_out/$TAG/parity_map100.json ] && cp gpurun_out/$TAG/parity_map100.json profiles/${TAG}_parity_map100.json
+[ -f gpurun_out/$TAG/parity_map50.json ] && cp gpurun_out/$TAG/parity_map50.json profiles/${TAG}_parity_map50.json
+[ -f gpurun_out/$TAG/stream_map100.txt ] && grep -v amdgpu gpurun_out/$TAG/stream_map100.txt > profiles/${TAG}_stream_map100.txt
+[ -f gpurun_out/$TAG/single_instance_times.txt ] && grep -v amdgpu gpurun_out/$TAG/single_instance_times.txt > profiles/${TAG}_single_instance_times.txt
+[ -f gpurun_out/$TAG/host_info.txt ] && cp gpurun_out/$TAG/host_info.txt profiles/${TAG}_host_info.txt
 [ -f gpurun_out/$TAG/phases_map100.txt ] && cp gpurun_out/$TAG/phases_map100.txt profiles/${TAG}_phase_profile_map100.txt
 [ -f gpurun_out/$TAG/phases_map50.txt ] && cp gpurun_out/$TAG/phases_map50.txt profiles/${TAG}_phase_profile_map50.txt
 grep -E "passed|failed" gpurun_out/$TAG/pytest_gpu.log | tail -1 > profiles/${TAG}_pytest_gpu_summary.txt
@@ -16,10 +21,10 @@ grep -E "^PASSED|^FAILED" gpurun_out/$TAG/pytest_gpu.log >> profiles/${TAG}_pyte
 for w in map100 map50; do [ -f gpurun_out/${TAG}s/bench_$w.json ] && tail -1 gpurun_out/${TAG}s/bench_$w.json > profiles/${TAG}_standin_bench_$w.json; done
 python - <<PY
 import json
-for w in ("map100", "map50", "synth1024"):
+for w in ("map100", "map50", "synth1024", "room50", "agents100"):
     d = json.loads(open("profiles/${TAG}_bench_%s.json" % w).read())
     r = d["roofline"]
-    print(w, "%.2f M it/s" % (d["value"] / 1e6), "%.1f ms" % d["ms_per_step"], "frac %.3f" % r["frac"], "pmc", r["pmc_source"])
+    print(w, "%.2f M it/s" % (d["value"] / 1e6), "%.1f ms" % d["ms_per_step"], "bound", r["bound"], "frac %.3f" % r["frac"], "pmc", r["pmc_source"])
 for w in ("map100", "map50"):
     try:
         d = json.loads(open("profiles/${TAG}_standin_bench_%s.json" % w).read())

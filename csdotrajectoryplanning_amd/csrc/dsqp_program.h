@@ -113,7 +113,6 @@ __device__ __forceinline__ void csdo_wave_sync() {   // orders the wave's own LD
 #define CSDO_DPP_PAIR_ODD 0xF5    /* quad_perm [1,1,3,3]: i | 1  */
 #define CSDO_DPP_PAIR_SWAP 0xB1   /* quad_perm [1,0,3,2]: i ^ 1  */
 #define CSDO_DPP_PREV 0x138       /* wave_shr:1: i - 1, lane 0 reads 0.0 */
-#define CSDO_DPP_ROW_PLUS2 0x102  /* row_shl:2: i + 2 inside the row of 16 lanes (beyond it: 0.0) */
 template <int CTRL>
 __device__ __forceinline__ double csdo_dpp_f64(const double v) {   // (bound_ctrl: a lane without a source reads 0 - and no copy of an old value is made)
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
@@ -166,7 +165,6 @@ __device__ __forceinline__ double csdo_dpp_f64(const double v) {   // (bound_ctr
 #define CSDO_DPP_PAIR_ODD 0xF5
 #define CSDO_DPP_PAIR_SWAP 0xB1
 #define CSDO_DPP_PREV 0x138
-#define CSDO_DPP_ROW_PLUS2 0x102
 // what v_mov_b32_dpp does with these controls: source lane of lane t (waves of 64), -1: none (reads 0.0)
 inline int csdo_dpp_src(const int ctrl, const int t, const int n_lanes) {
   const int lane = t & 63, base = t - lane;

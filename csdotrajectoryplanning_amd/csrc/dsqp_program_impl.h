@@ -1170,29 +1170,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               });
               CSDO_FOR(a, 6, { V.o[a] = qa[a] + qb[a]; });   // even lane t: pl(t); odd lane t: pr(t - 1)
             }
-            // level 2 hands its partials over in registers (the helper of node s - 2 is lane s - 1: wave_shr:1; node s + 2 is two
-            // lanes up in the same row of 16: row_shl:2); only the one that leaves the wave goes to LDS (for the hand-over sum)
-            if ((V.fl & (XF_WR << lev)) && (h != 2 || (t & 63) == 63)) {
+            if (V.fl & (XF_WR << lev)) {
               if (t & 1) CSDO_FOR(k, 6, { SH(pr, k, t - 1) = V.o[k]; });
               else CSDO_FOR(k, 6, { SH(pl, k, t) = V.o[k]; });
             }
-          }
-          if (h == 2) {
-            CSDO_XLANES(t) {
-              SolvRegs& V = CSDO_SS(t);
-              double left[6], right[6];
-              CSDO_FOR(k, 6, { left[k] = CSDO_XGET(CSDO_DPP_PREV, o, k); });
-              CSDO_FOR(k, 6, { right[k] = CSDO_XGET(CSDO_DPP_ROW_PLUS2, o, k); });
-              if (V.fl & (XF_ABS << 1)) CSDO_FOR(k, 6, { V.b[k] -= left[k]; });
-              if (V.fl & (XF_ABSR << 1)) CSDO_FOR(k, 6, { V.b[k] -= right[k]; });
-            }
-          } else {
-            CSDO_XLANES(t) {
-              SolvRegs& V = CSDO_SS(t);
-            CSDO_XSTEP_LDS(t)
-              if (V.fl & (XF_ABS << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - h); });
-              if (V.fl & (XF_ABSR << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + h); });
-            }
+          CSDO_XSTEP_LDS(t)
+            if (V.fl & (XF_ABS << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - h); });
+            if (V.fl & (XF_ABSR << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + h); });
           }
         }
       }

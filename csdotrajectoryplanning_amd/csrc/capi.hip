@@ -419,7 +419,7 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   // slower), then - after all first launches - the rest up to one workgroup per CU.  The second launch only gets CUs
   // that other groups release, so a group that finishes early hands its CUs over and nobody idles on a bad estimate.
   {
-    const double mode_cost[4] = {1.0, 1.2, 3.5, 5.5};   // cycles per ADMM iteration relative to mode 0 (measured: 16 k / 55 k / 87 k)
+    const double mode_cost[4] = {1.0, 1.2, 1.6, 5.5};   // CU time per agent and timestep relative to mode 0 (measured on the room set; mode 3: 87 k cycles per iteration against 16 k)
     std::vector<double> work(h->groups.size(), 0.0);
     double total = 0.0;
     for (size_t g = 0; g < h->groups.size(); ++g) {

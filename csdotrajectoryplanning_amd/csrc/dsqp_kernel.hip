@@ -38,7 +38,7 @@ size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) 
   const int st = (nt + 1) & ~1;
   // exchange vectors vec, pr, rhs, carry (6 each) + bounds of the home rows 22 (the t -> t-1 hand-over aliases them) +
   // the third of the factor that is not in the solver lane's registers 34 (mode 0); mode 3: vec, pr, rhs, carry, carry2
-  const size_t per_lane = mode == 3 ? 30 : (mode == 2 ? 60 : (mode == 1 ? 46 : (size_t)LD_block));
+  const size_t per_lane = mode == 3 ? 30 : (mode == 2 ? (size_t)LD_block2 : (mode == 1 ? (size_t)LD_block1 : (size_t)LD_block));
   const size_t n_obs_pad = (3 * (size_t)n_obs + 1) & ~(size_t)1, n_pc_pad = (3 * (size_t)n_planes + 1) & ~(size_t)1;
   const size_t planes = (mode == 0 && rows_lds) ? n_pc_pad + (size_t)LD_prow * n_planes : 0;   // rhs shares + duals / slacks
   return (per_lane * st + n_obs_pad + 32 + 2 * TAIL_N + TAIL_N * 38 + planes) * sizeof(double);

@@ -35,27 +35,27 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   sh.vec = aligned16(lds);
   sh.pl = sh.vec;       // aliases, see Shm
   sh.pr = aligned16(sh.vec + 6 * st);
-  sh.rhs = aligned16(sh.pr + 6 * st);
+  // (mode 2: the rhs shares of the row lanes wait in the right partials' array: written in the update, behind the solve's last
+  //  barrier, read by the timestep's solver lane before its wave writes any partial of the next solve, all writers of pr[t] being in
+  //  the wave of lane t)
+  sh.rhs = MODE == 2 ? sh.pr : aligned16(sh.pr + 6 * st);
   sh.carry = aligned16(sh.rhs + 6 * st);
   sh.red = sh.vec;
   double* rest = sh.carry + 6 * st;
-  if constexpr (MODE == 2) {   // the lean layout plus all of F_r (36 doubles per timestep); carry2 is only used between blocks
+  if constexpr (MODE == 2) {   // the lean layout plus the LDS part of the lane's second block; carry2 is only used between blocks
     sh.stash = sh.vec;
     sh.lohi = nullptr;
     sh.fx = aligned16(rest);
     sh.carry2 = sh.fx;
-    rest = sh.fx + 36 * st;
+    rest = sh.fx + LD_fx2 * st;
   } else if constexpr (MODE != 3) {
     sh.stash = sh.vec;
     sh.lohi = aligned16(rest);
     sh.carry2 = sh.lohi;
     rest = sh.lohi + 22 * st;
-    if constexpr (MODE == 0) {
-      sh.fx = aligned16(rest);
-      rest = sh.vec + LD_block * st;
-    } else {
-      sh.fx = nullptr;
-    }
+    sh.fx = aligned16(rest);
+    if constexpr (MODE == 0) rest = sh.vec + LD_block * st;
+    else rest = sh.fx + LD_fx1 * st;   // mode 1: the LDS part of the lane's second block only
   } else {
     sh.stash = sh.lohi = sh.fx = nullptr;
     sh.carry2 = aligned16(rest);

@@ -325,6 +325,16 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 #define CSDO_ER_REG 24   // measured again after the plane-pass fix (map100 set, ms per step): 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
 #endif
 constexpr int ER_REG = CSDO_ER_REG, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
+// The 768-thread class (residency mode 2, 168 registers per lane): NOTHING of the factor stays in registers across an iteration -
+// whatever part was declared lane state there, the allocator spilled and reloaded level by level.  The lane's level-1 block is
+// fetched from the workspace in one batch in front of each of its two uses, the block of its other level sits in LDS, all 36
+// entries (Shm::fx, LD_fx2 = 34 doubles per lane - 2 x odd: conflict-free 128-bit reads - and the two doubles per lane that
+// Shm::carry does not use); to make room the rows' rhs shares use the right partials' array (see Shm::rhs).
+// 18 + 34 = 52 doubles per timestep: horizons to 350 beside 238 obstacles; longer ones run mode 3.
+#if !defined(CSDO_ER_REG2)
+#define CSDO_ER_REG2 0
+#endif
+constexpr int ER_REG2 = CSDO_ER_REG2, FX_ER2 = 36 - ER_REG2;
 
 struct RowRegs {            // row lane of timestep t: the 16 home constraint rows and the 6 variables
   double c[NROW][3];        // scaled coefficients on own columns
@@ -341,10 +351,11 @@ struct RowRegs {            // row lane of timestep t: the 16 home constraint ro
 };
 struct SolvRegs {           // solver lane of timestep t during an ADMM block
   double b[6];              // rhs -> BCR work vector -> x_tilde
-  // Long-horizon modes (2, 3): BCR node t with both couplings, F_l = Sinv E_l in el (modes 2, 3 fetch F_r where they use it).
-  // Pair-split modes (0, 1): the two 6x6 blocks this LANE multiplies with, one per level it works at (see "pair-split solve"
-  // in dsqp_program_impl.h): el = the block of level 1, er = the first ER_REG entries of the block of the lane's level >= 2
-  // (the rest: LDS, Shm::fx; mode 1: the workspace)
+  // Mode 3 (horizons beyond 384, or a 768-thread agent whose obstacles leave no room): BCR node t with both couplings, F_l = Sinv E_l
+  // in el, F_r fetched from the workspace where it is used.
+  // Pair-split modes (0, 1, 2): the two 6x6 blocks this LANE multiplies with, one per level it works at (see "pair-split solve"
+  // in dsqp_program_impl.h): el = the block of level 1, er = the first ER_REG (mode 2: ER_REG2) entries of the block of the lane's
+  // level >= 2 (the rest: LDS, Shm::fx)
   double el[36];
   int ts0, ts1;             // plane range of this timestep (CSR offsets), for the rhs assembly
   double er[ER_REG];
@@ -382,7 +393,10 @@ enum WsSlot {
 constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + (CSDO_SINV_LDS ? 21 : 0) + 1) / 2) | 1),
               // the block's per-timestep arrays (vec .. fx) double as the factorisation's exchange columns, 78 fields x stride
               LD_block = (24 + LD_lohi + LD_fx) > 78 ? (24 + LD_lohi + LD_fx) : 78,
+              LD_fx2 = 34, LD_block2 = 18 + LD_fx2,   // mode 2: vec, pr (= rhs), carry (whose two spare doubles per lane hold the block's last two entries) + fx
+              LD_fx1 = 2 * (((FX_ER + 1) / 2) | 1), LD_block1 = 24 + LD_lohi + LD_fx1,   // mode 1: mode 0 without the pivot inverse (and the rows' state)
               LD_stash = 38, LD_tinv = 38, LD_prow = 10;
+static_assert(LD_block2 >= LD_stash, "the factorisation parks a 6x6 product and the packed pivot inverse per lane in the block's arrays");
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
 struct Shm {

@@ -16,8 +16,7 @@ namespace csdo {
 // F_r of node t: the solver lane's registers for the first ER_REG entries, LDS for the rest and for the pivot inverse;
 // everything from the workspace for long horizons
 // (MODE 2: the lean modes' layout - nothing of the factor in registers - with all of F_r in LDS, 36 doubles per timestep)
-#define FX2(k, t) sh.fx[(t) * 36 + (k)]
-#define ER(k, t) (MODE == 3 ? FE(36 + (k), t) : (MODE == 2 ? FX2(k, t) : ((k) < ER_REG ? V.er[(k) < ER_REG ? (k) : 0] : (MODE == 1 ? FE(36 + (k), t) : SH(fx, ((k) >= ER_REG ? (k) - ER_REG : 0), t)))))
+#define ER(k, t) FE(36 + (k), t)   /* one-lane form (mode 3): F_r of node t from the workspace */
 #define SINV(k, t) ((MODE >= 1 || !CSDO_SINV_LDS) ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 // set-up stage scratch, field-major over the ADMM block's exchange arrays (see "assemble the QP")
 #define SU(k, t) sh.vec[(size_t)(k) * (size_t)csdo_opaque_s(sh.stride) + (unsigned)(t)]
@@ -368,7 +367,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 double a = 0.0;
                 CSDO_FOR(k, 6, { a = fma(Sinv[sym(r, k)], Rl[k * 6 + c], a); });
                 STASH(r * 6 + c) = a;
-                if constexpr (MODE < 2) {  // F_l = Sinv * E_l, what the solve uses (pair-split modes: where its lane reads it)
+                if constexpr (MODE != 3) {  // F_l = Sinv * E_l, what the solve uses (pair-split modes: where its lane reads it)
                   PF_L(c * 6 + r, t) = a;
                   if (!has_r) PF_R(c * 6 + r, t) = (c >= 3) ? a : 0.0;
                 } else {
@@ -423,7 +422,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
               });
             });
             CSDO_STAGE();
-            if constexpr (MODE < 2) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = STASH(r * 6 + c); }); });
+            if constexpr (MODE != 3) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = STASH(r * 6 + c); }); });
             else CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { FR(c * 6 + r, t) = STASH(r * 6 + c); }); });
           }
 #undef STASH
@@ -607,7 +606,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       CSDO_SYNC();
     }
   }
-  if constexpr (MODE >= 2) {   // (node 0 is never eliminated: its lane's blocks are loaded with the others and never used)
+  if constexpr (MODE == 3) {   // (node 0 is never eliminated: its lane's blocks are loaded with the others and never used)
     CSDO_TLANES(t) {
       if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });
     }
@@ -712,7 +711,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   }
   CSDO_SYNC();
 
-  constexpr int n_block_fields = (MODE == 3 ? 30 : (MODE == 2 ? 60 : (MODE == 1 ? 46 : LD_block)));
+  constexpr int n_block_fields = (MODE == 3 ? 30 : (MODE == 2 ? LD_block2 : (MODE == 1 ? LD_block1 : LD_block)));
   // grow_box's per-obstacle step counts (BoxCache): the ADMM block's LDS arrays are idle whenever boxes are grown
 #if defined(CSDO_LANE_MODE_DEVICE)
   // (all but the last two fields of them: those carry the initial boxes' status flags, written while other lanes still grow)
@@ -1108,8 +1107,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // Barriers per solve: 3 (levels + gather | tail product beside the w pass | backward) instead of 2 log2(Nt / 6) + 2.
     // Measured: fixed-work iteration 10.45 -> 9.3 us on one instance alone, 2.5 % under a full batch.
     constexpr unsigned XF_ABS = 1u, XF_ABSR = 1u << 6, XF_WR = 1u << 12, XF_OWN = 1u << 18, XF_NR = 1u << 24;
-#define A2_LDS(k, tt) (MODE == 1 ? FE(72 + ER_REG + (k), tt) : SH(fx, (k), tt))   /* the block's entries beyond ER_REG */
-    auto solve_pair = [&](auto) __attribute__((always_inline)) {   // (generic: only instantiated for the modes that call it)
+    constexpr int XER = (MODE == 2) ? ER_REG2 : ER_REG, XFX = 36 - XER;   // the second block: entries in registers / elsewhere
+#define A2_LDS(k, tt) (*((MODE == 2 && (k) >= LD_fx2) ? &sh.carry[(tt) * LD_carry + 4 + ((k) >= LD_fx2 ? (k) - LD_fx2 : 0)] \
+                                                   : &sh.fx[(tt) * (MODE == 2 ? LD_fx2 : (MODE == 1 ? LD_fx1 : LD_fx)) + (k)]))   /* the block's entries beyond XER */
+    auto solve_pair = [&](auto before_last_barrier) __attribute__((always_inline)) {   // (generic: only instantiated for the modes that call it)
       CSDO_MARK("solve_begin");
       CSDO_PHASE(7);
 #if defined(CSDO_ABL_NOSOLVE)
@@ -1127,6 +1128,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
         CSDO_XLANES(t) {
           SolvRegs& V = CSDO_SS(t);
+          // (768-thread class, 168 registers per lane: the level-1 block is not kept across the iteration - as lane state it was
+          //  what the allocator spilled, reloaded entry by entry inside level 1: 6 k cycles against 1 k in the 512-thread class -
+          //  but fetched from the workspace in one batch in front of each of its two uses)
+          if constexpr (MODE == 2) CSDO_FOR(k, 36, { V.el[k] = FE(k, t < NtE ? t : NtE - 1); });
           CSDO_FOR(k, 6, { V.v[k] = CSDO_XGET(CSDO_DPP_PAIR_ODD, b, k); });   // both lanes of a pair: the odd node's rhs
         CSDO_XSTEP(t)
           {
@@ -1158,16 +1163,32 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_XSTEP(t)
             {
               const int tl = t < NtE ? t : NtE - 1;
-              double m2x[FX_ER > 0 ? FX_ER : 1];
-              CSDO_FOR(k, FX_ER, { m2x[k] = A2_LDS(k, tl); });
               double qa[6] = {0, 0, 0, 0, 0, 0}, qb[6] = {0, 0, 0, 0, 0, 0};
-#define A2(kk) ((kk) < ER_REG ? V.er[(kk) < ER_REG ? (kk) : 0] : m2x[(kk) >= ER_REG ? (kk) - ER_REG : 0])
-              CSDO_FOR(k, 3, {
-                CSDO_FOR(a, 6, {
-                  qa[a] = fma(A2(a * 6 + k), V.v[k], qa[a]);
-                  qb[a] = fma(A2(a * 6 + k + 3), V.v[k + 3], qb[a]);
+#define A2(kk) ((kk) < XER ? V.er[(kk) < XER ? (kk) : 0] : m2x[(kk) >= XER ? (kk) - XER : 0])
+              if constexpr (MODE == 2) {
+                // (168 registers per lane: two rows of the block at a time - every row is its own pair of accumulation chains -, so
+                //  that the part of the block that waits in LDS is never in registers all at once)
+                CSDO_FOR(a2, 3, {
+                  double rw[12];
+                  CSDO_FOR(e, 12, { rw[e] = (a2 * 12 + e) < XER ? V.er[(a2 * 12 + e) < XER ? (a2 * 12 + e) : 0] : A2_LDS((a2 * 12 + e) >= XER ? (a2 * 12 + e) - XER : 0, tl); });
+                  CSDO_FOR(k, 3, {
+                    CSDO_FOR(ah, 2, {
+                      qa[2 * a2 + ah] = fma(rw[ah * 6 + k], V.v[k], qa[2 * a2 + ah]);
+                      qb[2 * a2 + ah] = fma(rw[ah * 6 + k + 3], V.v[k + 3], qb[2 * a2 + ah]);
+                    });
+                  });
+                  CSDO_STAGE();
                 });
-              });
+              } else {
+                double m2x[XFX > 0 ? XFX : 1];
+                CSDO_FOR(k, XFX, { m2x[k] = A2_LDS(k, tl); });
+                CSDO_FOR(k, 3, {
+                  CSDO_FOR(a, 6, {
+                    qa[a] = fma(A2(a * 6 + k), V.v[k], qa[a]);
+                    qb[a] = fma(A2(a * 6 + k + 3), V.v[k + 3], qb[a]);
+                  });
+                });
+              }
               CSDO_FOR(a, 6, { V.o[a] = qa[a] + qb[a]; });   // even lane t: pl(t); odd lane t: pr(t - 1)
             }
             if (V.fl & (XF_WR << lev)) {
@@ -1328,8 +1349,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_XLANES(t) {
             SolvRegs& V = CSDO_SS(t);
             const int tl = t < NtE ? t : NtE - 1;
-            double m2x[FX_ER > 0 ? FX_ER : 1];
-            CSDO_FOR(k, FX_ER, { m2x[k] = A2_LDS(k, tl); });
             // the node's lane takes x of the left neighbour, its partner x of the right one - or, for a node without one, of
             // the left one again (second half of F_l, see the factorisation); lanes not at work read any valid slot
             const int n = t & ~1;
@@ -1338,9 +1357,22 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             CSDO_FOR(k, 6, { V.v[k] = SH(vec, k, src); });
             if (V.fl & (XF_NR << lev)) CSDO_FOR(k, 3, { V.v[3 + k] = 0.0; });
             CSDO_FOR(r, 6, { V.o[r] = V.b[r]; });
-            CSDO_FOR(c, 6, {
-              CSDO_FOR(r, 6, { V.o[r] = fma(-A2(c * 6 + r), V.v[c], V.o[r]); });
-            });
+            if constexpr (MODE == 2) {   // (two columns of the block at a time, see the forward sweep)
+              CSDO_FOR(c2, 3, {
+                double cw[12];
+                CSDO_FOR(e, 12, { cw[e] = (c2 * 12 + e) < XER ? V.er[(c2 * 12 + e) < XER ? (c2 * 12 + e) : 0] : A2_LDS((c2 * 12 + e) >= XER ? (c2 * 12 + e) - XER : 0, tl); });
+                CSDO_FOR(ch, 2, {
+                  CSDO_FOR(r, 6, { V.o[r] = fma(-cw[ch * 6 + r], V.v[2 * c2 + ch], V.o[r]); });
+                });
+                CSDO_STAGE();
+              });
+            } else {
+              double m2x[XFX > 0 ? XFX : 1];
+              CSDO_FOR(k, XFX, { m2x[k] = A2_LDS(k, tl); });
+              CSDO_FOR(c, 6, {
+                CSDO_FOR(r, 6, { V.o[r] = fma(-A2(c * 6 + r), V.v[c], V.o[r]); });
+              });
+            }
           CSDO_XSTEP(t)
             double ub[6];
             CSDO_FOR(k, 6, { ub[k] = CSDO_XGET(CSDO_DPP_PAIR_SWAP, o, k); });
@@ -1352,6 +1384,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
         CSDO_XLANES(t) {   // level 1: x of the odd nodes, summed and stored by the even lane of the pair
           SolvRegs& V = CSDO_SS(t);
+          if constexpr (MODE == 2) CSDO_FOR(k, 36, { V.el[k] = FE(k, t < NtE ? t : NtE - 1); });
           int src = (t & 1) ? (((t + 1) < Nt) ? t + 1 : t - 1) : t;
           src = src >= NtE ? NtE - 1 : src;
           CSDO_FOR(k, 6, { V.v[k] = SH(vec, k, src); });
@@ -1369,6 +1402,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_XT(7);   // backward sweep
       CSDO_PHASE(14);
+      before_last_barrier();
       CSDO_SYNC();
       CSDO_PHASE(8);
 #undef A2
@@ -1584,8 +1618,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
     };
 
-    auto solve = [&]() __attribute__((always_inline)) {
-      if constexpr (MODE < 2) solve_pair(0);
+    // `before_last_barrier`: what the row waves do while they wait for the backward sweep (pair-split modes)
+    auto solve = [&](auto before_last_barrier) __attribute__((always_inline)) {
+      if constexpr (MODE != 3) solve_pair(before_last_barrier);
       else solve_lds(0);
     };
 
@@ -1993,11 +2028,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         }
         publish_rhs(S, t);
       }
-      if constexpr (MODE >= 2) {
+      if constexpr (MODE == 3) {
         CSDO_SLANES(t) {  // load the solver-lane cache: F_l of the node in registers
           SolvRegs& V = CSDO_SS(t);
           CSDO_FOR(k, 36, { V.el[k] = FE(k, t); });
-          if constexpr (MODE == 2) CSDO_FOR(k, 36, { FX2(k, t) = FE(36 + k, t); });
           V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
           V.ts1 = csdo_keep(tstart[t + 1]);
         }
@@ -2007,12 +2041,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_XLANES(t) {
           SolvRegs& V = CSDO_SS(t);
           const int tl = t < NtE ? t : NtE - 1;   // (threads beyond the horizon take part in the wave's moves: any valid address)
-          CSDO_FOR(k, 36, { V.el[k] = FE(k, tl); });
-          CSDO_FOR(k, ER_REG, { V.er[k] = FE(72 + k, tl); });
-          if constexpr (MODE == 0) {
+          if constexpr (MODE != 2) CSDO_FOR(k, 36, { V.el[k] = FE(k, tl); });   // (mode 2 fetches it where it is used)
+          CSDO_FOR(k, XER, { V.er[k] = FE(72 + k, tl); });
+          {
             if (t < NtE) {
-              CSDO_FOR(k, FX_ER, { SH(fx, k, t) = FE(72 + ER_REG + k, t); });
-              if constexpr (CSDO_SINV_LDS != 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
+              CSDO_FOR(k, XFX, { A2_LDS(k, t) = FE(72 + XER + k, t); });
+              if constexpr (CSDO_SINV_LDS != 0 && MODE == 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
             }
           }
           V.ts0 = V.ts1 = 0;
@@ -2112,7 +2146,40 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           else add_planes(std::false_type{});
           CSDO_FOR(j, 6, { V.b[j] = r6[j]; });
         }
-        solve();
+        // (modes 2, 3: the row lanes stream their rows' coefficients and bounds from the workspace, see the update; on the device the
+        //  first two groups of rows are fetched while the row waves wait for the backward sweep)
+#define CSDO_ROWGROUP(name) double name##c[3][3], name##n[3], name##l[3], name##h[3]
+        CSDO_ROWGROUP(ga); CSDO_ROWGROUP(gb); CSDO_ROWGROUP(gd);
+#undef CSDO_ROWGROUP
+        auto load_rows = [&](const int t, auto i0_c, auto n_c, double (&gc)[3][3], double (&gcn)[3], double (&glo)[3], double (&ghi)[3]) __attribute__((always_inline)) {
+          constexpr int i0 = decltype(i0_c)::value, n = decltype(n_c)::value;
+          CSDO_FOR(r, n, {
+            constexpr int i = i0 + r;
+            CSDO_FOR(s_, 3, {
+              if constexpr (row_col(i, s_) >= 0) gc[r][s_] = WS(W_C + 3 * i + s_, t);
+              else gc[r][s_] = 0.0;
+            });
+            if constexpr (i < 4) gcn[r] = WS(W_CN + i, t);
+            else gcn[r] = 0.0;
+            if constexpr (i < 13) glo[r] = WS(W_LO + i, t);
+            if constexpr (i >= 7) ghi[r] = WS(W_HI + i, t);
+            if constexpr (i < 7) ghi[r] = glo[r];
+            if constexpr (i >= 13) glo[r] = -ghi[r];
+          });
+        };
+#if defined(CSDO_LANE_MODE_DEVICE)
+        constexpr bool rows_prefetched = (MODE == 2) && (ROLE == ROLE_ROW);
+#else
+        constexpr bool rows_prefetched = false;
+#endif
+        solve([&]() __attribute__((always_inline)) {
+          if constexpr (rows_prefetched) {
+            CSDO_LANES_HOT(t) {
+              load_rows(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, gac, gan, gal, gah);
+              load_rows(t, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, gbc, gbn, gbl, gbh);
+            }
+          }
+        });
         CSDO_PHASE(9);
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");
@@ -2125,14 +2192,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #endif
         CSDO_LANES_HOT(t) {
           LaneState& S = CSDO_LS(t);
-          // mode 3: the 22 bounds of the home rows come from the workspace; one batch of loads in front of everything
-          // else of the update (a load per row inside the loop below costs an L2 round trip each)
-          double bnd[22];
-          if constexpr (MODE >= 2) {
-            CSDO_FOR(k, 13, { bnd[k] = WS(W_LO + k, t); });
-            CSDO_FOR(k, 6, { bnd[13 + k] = WS(W_HI + 7 + k, t); });
-            CSDO_FOR(k, 3, { bnd[19 + k] = WS(W_HI + 13 + k, t); });
-          }
           double xt[6], xn[4] = {0, 0, 0, 0};
           CSDO_FOR(k, 6, { xt[k] = SH(vec, k, t); });
           if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
@@ -2147,39 +2206,74 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           // the interior): their coefficients, bounds, duals and slacks are all zero (assemble_home_rows, warm start) and stay
           // zero through the formulas below, and straight-line code lets the rows' dependent chains overlap (16 basic blocks
           // with an exec-mask test each could not).
-          CSDO_FOR(i, NROW, {
-            {
-              double zt = 0.0;
-              CSDO_FOR(s_, 3, {
-                if constexpr (row_col(i, s_) >= 0) zt = fma(S.c[i][s_], xt[row_col(i, s_)], zt);
-              });
-              if constexpr (i < 4) zt = fma(S.cn[i], xn[i], zt);
-              const double rh = rho_row<i>(S, rho, rho_eq);
-              const double rinv = rho_row<i>(S, rinv_in, rinv_eq);   // = 1.0 / rh (rho_inv_vec of OSQP)
-              const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
-              double lo_i, hi_i;
-              // bounds in the packed order of Shm::lohi: from LDS, or (mode 3) from the batch fetched above
-              if constexpr (i < 7) lo_i = hi_i = (MODE >= 2) ? bnd[i] : SH(lohi, i, t);
+          auto do_row = [&](auto i_c, const double c0, const double c1, const double c2, const double cni, const double lo_i,
+                            const double hi_i) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_c)::value;
+            const double ci[3] = {c0, c1, c2};
+            double zt = 0.0;
+            CSDO_FOR(s_, 3, {
+              if constexpr (row_col(i, s_) >= 0) zt = fma(ci[s_], xt[row_col(i, s_)], zt);
+            });
+            if constexpr (i < 4) zt = fma(cni, xn[i], zt);
+            const double rh = rho_row<i>(S, rho, rho_eq);
+            const double rinv = rho_row<i>(S, rinv_in, rinv_eq);   // = 1.0 / rh (rho_inv_vec of OSQP)
+            const double zr = alpha * zt + (1.0 - alpha) * S.z[i];
+            const double zn = hot_min(hot_max(zr + rinv * S.y[i], lo_i), hi_i);
+            const double d = rh * (zr - zn);
+            if constexpr (keep_dy) WS(C_DY + i, t) = d;
+            S.y[i] += d;
+            S.z[i] = zn;
+            const double g = fma(rh, zn, -S.y[i]);
+            CSDO_FOR(s_, 3, {
+              if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(ci[s_], g, r6[row_col(i, s_)]);
+            });
+            if constexpr (i < 4) kin[i] = cni * g;
+          };
+          if constexpr (MODE < 2) {
+            CSDO_FOR(i, NROW, {
+              double lo_i, hi_i;   // bounds in the packed order of Shm::lohi
+              if constexpr (i < 7) lo_i = hi_i = SH(lohi, i, t);
               if constexpr (i >= 7 && i < 13) {
-                lo_i = (MODE >= 2) ? bnd[i] : SH(lohi, i, t);
-                hi_i = (MODE >= 2) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                lo_i = SH(lohi, i, t);
+                hi_i = SH(lohi, i + 6, t);
               }
               if constexpr (i >= 13) {
-                hi_i = (MODE >= 2) ? bnd[i + 6] : SH(lohi, i + 6, t);
+                hi_i = SH(lohi, i + 6, t);
                 lo_i = -hi_i;
               }
-              const double zn = hot_min(hot_max(zr + rinv * S.y[i], lo_i), hi_i);
-              const double d = rh * (zr - zn);
-              if constexpr (keep_dy) WS(C_DY + i, t) = d;
-              S.y[i] += d;
-              S.z[i] = zn;
-              const double g = fma(rh, zn, -S.y[i]);
-              CSDO_FOR(s_, 3, {
-                if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(S.c[i][s_], g, r6[row_col(i, s_)]);
-              });
-              if constexpr (i < 4) kin[i] = S.cn[i] * g;
+              do_row(i_c, S.c[i][0], S.c[i][1], S.c[i][2], (i < 4) ? S.cn[i < 4 ? i : 0] : 0.0, lo_i, hi_i);
+            });
+          } else {
+            // Long horizons (168 or 128 registers per lane): duals, slacks and the iterate stay in registers, the rows' coefficients
+            // and bounds - read-only during a QP, 53 doubles - are STREAMED from the workspace in seven groups of rows, the loads of
+            // a group issued a group ahead of its use.  (With the coefficients among the lane's registers the allocator spilled a
+            // third of the row state and reloaded it where it was used: 65 scratch loads per iteration, each waited for on its
+            // own - 21 k of the 55 k cycles of an iteration of this class.)
+            auto use_rows = [&](auto i0_c, auto n_c, const double (&gc)[3][3], const double (&gcn)[3], const double (&glo)[3], const double (&ghi)[3]) __attribute__((always_inline)) {
+              constexpr int i0 = decltype(i0_c)::value, n = decltype(n_c)::value;
+              CSDO_FOR(r, n, { do_row(std::integral_constant<int, i0 + r>{}, gc[r][0], gc[r][1], gc[r][2], gcn[r], glo[r], ghi[r]); });
+            };
+#define CSDO_LOAD_ROWS(name, I0_, N_) load_rows(t, std::integral_constant<int, I0_>{}, std::integral_constant<int, N_>{}, name##c, name##n, name##l, name##h); CSDO_STAGE()
+#define CSDO_USE_ROWS(name, I0_, N_) use_rows(std::integral_constant<int, I0_>{}, std::integral_constant<int, N_>{}, name##c, name##n, name##l, name##h); CSDO_STAGE()
+            if (!rows_prefetched) {
+              CSDO_LOAD_ROWS(ga, 0, 2);
+              CSDO_LOAD_ROWS(gb, 2, 2);
             }
-          });
+            CSDO_USE_ROWS(ga, 0, 2);
+            CSDO_LOAD_ROWS(gd, 4, 3);
+            CSDO_USE_ROWS(gb, 2, 2);
+            CSDO_LOAD_ROWS(ga, 7, 2);
+            CSDO_USE_ROWS(gd, 4, 3);
+            CSDO_LOAD_ROWS(gb, 9, 2);
+            CSDO_USE_ROWS(ga, 7, 2);
+            CSDO_LOAD_ROWS(gd, 11, 2);
+            CSDO_USE_ROWS(gb, 9, 2);
+            CSDO_LOAD_ROWS(ga, 13, 3);
+            CSDO_USE_ROWS(gd, 11, 2);
+            CSDO_USE_ROWS(ga, 13, 3);
+#undef CSDO_LOAD_ROWS
+#undef CSDO_USE_ROWS
+          }
           CSDO_FOR(j, 6, { SH(rhs, j, t) = r6[j]; });
           CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
         }
@@ -2375,7 +2469,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       B.prof[(int64_t)agent * 48 + 16 + lv] = lvl_fwd;
       B.prof[(int64_t)agent * 48 + 32 + lv] = lvl_bwd;
     }
-    if constexpr (MODE < 2) {
+    if constexpr (MODE != 3) {
       if (B.prof && (ts == 1 || ts == 129)) for (int k = 0; k < 8; ++k) B.prof[(int64_t)agent * 48 + (ts == 1 ? 16 : 32) + k] = xs_acc[k];
     }
   }

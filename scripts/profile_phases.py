@@ -14,7 +14,10 @@ from csdotrajectoryplanning_amd.solver import DsqpHandle  # noqa: E402
 NAMES = ["other", "corridor", "assemble", "ruiz", "warmstart", "factor", "rhs", "solve_fwd", "solve_bwd", "update",
          "info/check", "bookkeeping", "hot load/save", "fwd barrier", "bwd barrier"]
 which = sys.argv[1] if len(sys.argv) > 1 else "map100"
-world, info = (workloads.map100_world(0) if which == "map100" else workloads.build_world(workloads.MAP50_AGENTS25, 0))
+if which in ("map100", "map50"):
+    world, info = (workloads.map100_world(0) if which == "map100" else workloads.build_world(workloads.MAP50_AGENTS25, 0))
+else:   # any workload of workloads.workload_jobs, world index in argv[2]
+    world, info = workloads.build_job(workloads.workload_jobs(which)[int(sys.argv[2]) if len(sys.argv) > 2 else 0])
 h = DsqpHandle(0)
 h.upload([world])
 h.run()

@@ -62,7 +62,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     sh.vec = lds.data();
     sh.pl = sh.vec;
     sh.pr = sh.vec + 6 * st;
-    sh.rhs = sh.pr + 6 * st;
+    sh.rhs = mode == 2 ? sh.pr : sh.pr + 6 * st;
     sh.carry = sh.rhs + 6 * st;
     sh.red = sh.vec;
     double* rest = sh.carry + 6 * st;
@@ -70,16 +70,15 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
       sh.stash = sh.vec;
       sh.fx = rest;
       sh.carry2 = sh.fx;
-      rest = sh.fx + 36 * st;
+      rest = sh.fx + LD_fx2 * st;
     } else if (mode != 3) {
       sh.stash = sh.vec;
       sh.lohi = rest;
       sh.carry2 = sh.lohi;
       rest = sh.lohi + 22 * st;
-      if (mode == 0) {
-        sh.fx = rest;
-        rest = sh.vec + LD_block * st;
-      }
+      sh.fx = rest;
+      if (mode == 0) rest = sh.vec + LD_block * st;
+      else rest = sh.fx + LD_fx1 * st;
     } else {
       sh.carry2 = rest;
       rest = sh.carry2 + 6 * st;

@@ -63,21 +63,21 @@ def _one_qp(world):
 
 
 def test_lds_residency_modes_are_bit_identical(emu, veh_parm):
-    """The residency modes of the ADMM block (agent_program MODE 0, 1 / 2, 3: which operands come from LDS / registers and
+    """The residency modes of the ADMM block (agent_program MODE 0, 1, 2 / 3: which operands come from LDS / registers and
     which from the workspace) only change where the same doubles are read from - within each of the two forms of the solve:
-    modes 0 and 1 run the pair-split solve, modes 2 and 3 (long horizons) the one-lane form, which absorbs the partials of a
+    modes 0, 1 and 2 run the pair-split solve, mode 3 (horizons beyond 384) the one-lane form, which absorbs the partials of a
     node at a multiple of 64 in a different order (dsqp_program_impl.h: "pair-split solve"); across the two forms the results
     agree to rounding."""
     veh, parm = veh_parm
     world, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
     assert world.Nt > 64                     # (a node at 64 exists: the two forms do differ)
-    ref = {0: emu.solve(world, 0), 2: emu.solve(world, 2)}
-    for mode in (10, 1, 3):   # 10: mode 0 with the inter-vehicle rows' state in LDS; 2: the lean layout with F_r in LDS
-        got, r = emu.solve(world, mode), ref[2 if mode == 3 else 0]
-        assert np.array_equal(r.solutions, got.solutions) and np.array_equal(r.corridors, got.corridors)
-        assert np.array_equal(r.admm_iters, got.admm_iters) and np.array_equal(r.last_status, got.last_status)
+    ref = emu.solve(world, 0)
+    for mode in (10, 1, 2):   # 10: mode 0 with the inter-vehicle rows' state in LDS; 2: the 768-thread class's layout
+        got = emu.solve(world, mode)
+        assert np.array_equal(ref.solutions, got.solutions) and np.array_equal(ref.corridors, got.corridors)
+        assert np.array_equal(ref.admm_iters, got.admm_iters) and np.array_equal(ref.last_status, got.last_status)
     first = lambda m: emu.solve(_one_qp(world), m)
-    a, b = first(0), first(2)
+    a, b = first(0), first(3)
     assert np.array_equal(a.admm_iters, b.admm_iters) and np.abs(a.solutions - b.solutions).max() < 1e-9
 
 

@@ -34,15 +34,15 @@ def test_streamed_do_phase_returns_the_bits_of_the_batch(gpu_handle):
     writes into the first call's arrays; a job smaller than the number of chunks; a job of mixed kernel classes."""
     items, worlds = _items_and_worlds("map50", 7)
     ref = gpu_handle.solve_batch(worlds)
-    got, tm = gpu_handle.do_phase_stream(items, worlds[0].veh, worlds[0].parm, single_launch_if_mixed=False)
+    got, tm = gpu_handle.do_phase_stream(items, worlds[0].veh, worlds[0].parm, single_launch_if_mixed=False, min_first_agents=0)
     sizes = [c["worlds"] for c in tm["chunks"]]
     assert len(sizes) == 3 and sum(sizes) == 7 and sizes == sorted(sizes) and sizes[0] == 1, sizes
     assert tm["first_launch"] < tm["total"]
     assert all(_same(g, r) for g, r in zip(got, ref))
     order = [6, 2, 4, 0, 5, 1, 3]
-    got2, _ = gpu_handle.do_phase_stream(items, worlds[0].veh, worlds[0].parm, order=order, out=got, single_launch_if_mixed=False)
+    got2, _ = gpu_handle.do_phase_stream(items, worlds[0].veh, worlds[0].parm, order=order, out=got, single_launch_if_mixed=False, min_first_agents=0)
     assert all(g2 is g for g2, g in zip(got2, got)) and all(_same(g, r) for g, r in zip(got2, ref))
-    got3, tm3 = gpu_handle.do_phase_stream(items[:2], worlds[0].veh, worlds[0].parm, single_launch_if_mixed=False)
+    got3, tm3 = gpu_handle.do_phase_stream(items[:2], worlds[0].veh, worlds[0].parm, single_launch_if_mixed=False, min_first_agents=0)
     assert [c["worlds"] for c in tm3["chunks"]] == [1, 1] and all(_same(g, r) for g, r in zip(got3, ref[:2]))
     # mixed kernel classes in one streamed job: the map100 worlds run in the 512-thread class, map50's mostly in the 256-thread one
     items100, worlds100 = _items_and_worlds("map100", 2)
@@ -50,7 +50,7 @@ def test_streamed_do_phase_returns_the_bits_of_the_batch(gpu_handle):
     # (one batch = one parameter block: both sets use the default vehicle and QP parameters)
     refm = gpu_handle.solve_batch(mixed_worlds)
     gotm, _ = gpu_handle.do_phase_stream(mixed_items, worlds[0].veh, worlds[0].parm, fractions=(0.2, 0.4, 0.4),
-                                         single_launch_if_mixed=False)
+                                         single_launch_if_mixed=False, min_first_agents=0)
     assert all(_same(g, r) for g, r in zip(gotm, refm))
     # the default: only a job of ONE kernel class is streamed (horizons 129 .. 234, known from the coarse paths); map50's worlds
     # (horizons below 129, two classes) are bridged on the host pool and solved by one launch, map100's are streamed
@@ -58,8 +58,11 @@ def test_streamed_do_phase_returns_the_bits_of_the_batch(gpu_handle):
     assert all(_same(g, r) for g, r in zip(gotd, ref)) and tmd["streamed"] is False and len(tmd["chunks"]) == 1
     items100b, worlds100b = _items_and_worlds("map100", 4)
     ref100 = gpu_handle.solve_batch(worlds100b)
-    got100, tm100 = gpu_handle.do_phase_stream(items100b, worlds100b[0].veh, worlds100b[0].parm)
+    got100, tm100 = gpu_handle.do_phase_stream(items100b, worlds100b[0].veh, worlds100b[0].parm, min_first_agents=0)
     assert all(_same(g, r) for g, r in zip(got100, ref100)) and tm100["streamed"] is True and len(tm100["chunks"]) == 3
+    # the default: the first chunk is enlarged until it fills the GPU (about 230 agents) - these 200 agents are one chunk
+    got100, tm100 = gpu_handle.do_phase_stream(items100b, worlds100b[0].veh, worlds100b[0].parm)
+    assert all(_same(g, r) for g, r in zip(got100, ref100)) and [c["worlds"] for c in tm100["chunks"]] == [4]
 
 
 def test_run_async_wait_and_their_guards(gpu_handle):

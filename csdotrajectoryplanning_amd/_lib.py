@@ -16,7 +16,7 @@ class CsdoError(RuntimeError):
 
 
 _ERR = {abi.CSDO_EINVAL: "invalid argument", abi.CSDO_ENODEV: "no usable HIP device (MI355X required)",
-        abi.CSDO_ENOMEM: "allocation failed", abi.CSDO_ELIMIT: "problem exceeds a compiled limit (Nt > 512)",
+        abi.CSDO_ENOMEM: "allocation failed", abi.CSDO_ELIMIT: "problem exceeds a compiled limit (Nt > 512, or an obstacle list that does not fit the LDS beside the horizon)",
         abi.CSDO_EDEVICE: "HIP kernel launch or execution failed"}
 
 

@@ -46,7 +46,7 @@ extern "C" {
 #define CSDO_EINVAL (-1)   /* bad argument (null pointer, Nt < 2, sizes inconsistent) */
 #define CSDO_ENODEV (-2)   /* no HIP device / device error */
 #define CSDO_ENOMEM (-3)   /* device or host allocation failed */
-#define CSDO_ELIMIT (-4)   /* problem exceeds a compiled limit (Nt > CSDO_MAX_NT) */
+#define CSDO_ELIMIT (-4)   /* problem exceeds a compiled limit: Nt > CSDO_MAX_NT, or a world whose obstacle list does not fit the LDS beside its horizon (csdo_dsqp_last_limit) */
 #define CSDO_EDEVICE (-5)  /* kernel launch / execution failed */
 
 #define CSDO_MAX_NT 512    /* longest supported horizon (one lane per timestep, <= 512 lanes per agent) */

@@ -416,7 +416,7 @@ def main():
                         "results_equal_the_resident_batch": bool(same),
                         "note": "best of 3 after a first pass; host wall clock from the coarse paths to the results in the "
                                 "caller's arrays; chunk k + 1 is bridged (host threads), packed and copied under chunk k's solve; "
-                                "a job of several kernel classes (in_chunks false) is bridged on the host pool and solved by "
+                                "a job of several kernel classes (in_chunks false) is bridged by one device call and solved by "
                                 "one launch instead"}
         e2e = {"total_ms": (streamed["total_ms"] if streamed else tot * 1e3),
                "streamed": streamed,

@@ -131,6 +131,21 @@ class DsqpHandle:
             mixed_by_horizon = not all(128 < nt <= 234 for nt in nts)
         else:
             mixed_by_horizon = False
+        if mixed_by_horizon:
+            # known before anything is bridged: the device bridge of all worlds in one call (csdo_preprocess_device_batch), one launch
+            tb = time.perf_counter()
+            bridged = self.interpolate_and_planes_batch([items[i] for i in idx], veh, parm)
+            tu = time.perf_counter()
+            self.upload([b[0] for b in bridged])
+            tr = time.perf_counter()
+            kern = self.run()
+            kernel_end = time.perf_counter() - t0
+            got = self.download(out=None if out is None else [out[i] for i in idx])
+            sols = [None] * n
+            for i, s_ in zip(idx, got):
+                sols[i] = s_
+            return sols, {"first_launch": tr - t0, "kernels_done": kernel_end, "total": time.perf_counter() - t0, "streamed": False,
+                          "chunks": [{"worlds": n, "bridge": tu - tb, "upload": tr - tu, "kernel": kern}]}
         timing = {"first_launch": None, "chunks": []}
         inflight = []
         next_lane = 0

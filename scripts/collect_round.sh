@@ -16,6 +16,8 @@ done
 [ -f gpurun_out/$TAG/host_info.txt ] && cp gpurun_out/$TAG/host_info.txt profiles/${TAG}_host_info.txt
 [ -f gpurun_out/$TAG/phases_map100.txt ] && cp gpurun_out/$TAG/phases_map100.txt profiles/${TAG}_phase_profile_map100.txt
 [ -f gpurun_out/$TAG/phases_map50.txt ] && cp gpurun_out/$TAG/phases_map50.txt profiles/${TAG}_phase_profile_map50.txt
+[ -f gpurun_out/$TAG/phases_room50_long.txt ] && cp gpurun_out/$TAG/phases_room50_long.txt profiles/${TAG}_phase_profile_room50_long_horizons.txt
+[ -f gpurun_out/$TAG/group_times_room50.txt ] && grep -v amdgpu gpurun_out/$TAG/group_times_room50.txt > profiles/${TAG}_group_times_room50.txt
 grep -E "passed|failed" gpurun_out/$TAG/pytest_gpu.log | tail -1 > profiles/${TAG}_pytest_gpu_summary.txt
 grep -E "^PASSED|^FAILED" gpurun_out/$TAG/pytest_gpu.log >> profiles/${TAG}_pytest_gpu_summary.txt
 for w in map100 map50; do [ -f gpurun_out/${TAG}s/bench_$w.json ] && tail -1 gpurun_out/${TAG}s/bench_$w.json > profiles/${TAG}_standin_bench_$w.json; done

@@ -31,3 +31,5 @@ timeout 600 python scripts/profile_phases_sum.py 0,2,3,4,5,6,7,9 map50 > $O/phas
 timeout 600 python scripts/stream_fractions.py map100 "0.08,0.27,0.65" > $O/stream_map100.txt 2>&1
 timeout 900 python scripts/authors_sweep.py $O/authors_sweep.json > $O/authors_sweep.log 2>&1
 timeout 300 python scripts/single_instance_times.py > $O/single_instance_times.txt 2>&1
+timeout 600 python scripts/profile_phases_sum.py 1,2 room50 > $O/phases_room50_long.txt 2>&1
+timeout 300 python scripts/group_times.py room50 > $O/group_times_room50.txt 2>&1

@@ -1196,8 +1196,21 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               else CSDO_FOR(k, 6, { SH(pl, k, t) = V.o[k]; });
             }
           CSDO_XSTEP_LDS(t)
-            if (V.fl & (XF_ABS << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pr, k, t - h); });
-            if (V.fl & (XF_ABSR << lev)) CSDO_FOR(k, 6, { V.b[k] -= SH(pl, k, t + h); });
+            {
+              // both partials in flight at once: a lane that takes none of the two reads six zeros instead (the hand-over slot of
+              // node 0, which has no left neighbours: zero for the whole solve) and subtracts them - b - 0.0 is b - so the wave waits
+              // for LDS once per level, not once per side
+              const double* const zeros = sh.tvec + TAIL_N;
+              const double* const pa = (V.fl & (XF_ABS << lev)) ? &SH(pr, 0, t - h) : zeros;
+              const double* const pb = (V.fl & (XF_ABSR << lev)) ? &SH(pl, 0, t + h) : zeros;
+              double xa[6], xb[6];
+              CSDO_FOR(k, 6, {
+                xa[k] = pa[k];
+                xb[k] = pb[k];
+              });
+              CSDO_FOR(k, 6, { V.b[k] -= xa[k]; });
+              CSDO_FOR(k, 6, { V.b[k] -= xb[k]; });
+            }
           }
         }
       }

@@ -2130,11 +2130,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // ---- rhs of the reduced system: the solver lane adds the kinematic share of t-1 and its planes' shares to what
         // its row lane left in sh.rhs (previous update / block load); no row-lane phase, no barrier in between
         CSDO_MARK("rhs");
-        CSDO_SLANES_HOT(t) {
+        CSDO_SLANES(t) {   // (the opaque lane index: with the plain one the LDS addresses of rhs and carry are hoisted out of the block's loop, spilled, and reloaded from scratch here - three waits in a row at the head of every iteration)
           SolvRegs& V = CSDO_SS(t);
           double r6[6];
           CSDO_FOR(j, 6, { r6[j] = SH(rhs, j, t); });
-          if (t > 0) CSDO_FOR(k, 4, { r6[k] += SH(carry, k, t - 1); });
+          if (t > 0) {   // (both halves in flight before the first is used)
+            double cr[4];
+            CSDO_FOR(k, 4, { cr[k] = SH(carry, k, t - 1); });
+            CSDO_STAGE();
+            CSDO_FOR(k, 4, { r6[k] += cr[k]; });
+          }
           // the planes' shares, three planes per round trip (added one by one in the planes' order, as before: a timestep in a
           // cluster of vehicles has several planes, and one LDS - or workspace - round trip per plane was the wave's critical path)
           auto add_planes = [&](auto lds_c) __attribute__((always_inline)) {

@@ -254,10 +254,10 @@ def test_gpu_error_codes(gpu_handle, veh_parm):
     assert _lib.lib().csdo_dsqp_solve(gpu_handle._h, C.byref(p), C.byref(sol._c)) == abi.CSDO_EINVAL  # Nt < 2
 
 
-@pytest.mark.parametrize("Nt,per_lane", [(100, 60), (200, 60), (300, 30)])
+@pytest.mark.parametrize("Nt,per_lane", [(100, 52), (200, 52), (300, 30)])
 def test_obstacle_count_at_which_a_world_no_longer_fits(gpu_handle, veh_parm, Nt, per_lane):
     """CSDO_ELIMIT at upload: the obstacle list is staged in LDS beside the per-timestep arrays of the leanest residency mode of
-    the agent's class (512 threads: mode 1, 60 doubles per timestep; the wide classes: mode 3, 30), the tail (1472 doubles) and
+    the agent's class (512 threads: mode 1, 52 doubles per timestep; the wide classes: mode 3, 30), the tail (1472 doubles) and
     nothing else.  The largest obstacle count that fits is pinned here for three horizons; one world beyond it rejects the
     whole batch, nothing is launched, and csdo_dsqp_last_limit says which world it was."""
     from csdotrajectoryplanning_amd import _lib
@@ -269,7 +269,7 @@ def test_obstacle_count_at_which_a_world_no_longer_fits(gpu_handle, veh_parm, Nt
     n_fit = (cap - fixed) // 8 // 3 + 2
     while ((3 * n_fit + 1) & ~1) * 8 + fixed > cap:        # (the staged list is padded to an even number of doubles)
         n_fit -= 1
-    assert {100: 4333, 200: 2333, 300: 3333}[Nt] == n_fit      # the capability, in numbers
+    assert {100: 4600, 200: 2866, 300: 3333}[Nt] == n_fit      # the capability, in numbers
 
     def world(n_obs):
         x0 = np.zeros((1, Nt, 6))

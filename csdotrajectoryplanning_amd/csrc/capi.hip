@@ -84,7 +84,12 @@ struct csdo_handle_s {
   bool uploaded = false;
   int n_worlds = 0;
   double last_kernel_s = 0.0;
-  DevBuf agents, worlds, x0, planes, tstart, obstacles, rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, order_d, queues;
+  // inputs: ONE device arena filled by ONE copy (small copies are done by blit kernels, which wait for a CU while another batch's
+  // persistent workgroups hold all of them: 8 ms for the upload of a streamed chunk); in_off: agents, worlds, x0, planes, tstart,
+  // obstacles, order
+  DevBuf in_arena;
+  size_t in_off[7] = {0, 0, 0, 0, 0, 0, 0};
+  DevBuf rows_ws, fac_ws, sol, corr, sqp, admm, stat, legal, ticks, queues;
   DevBuf box_pts, box_obs, box_out, box_status;
   DevBuf k0_centres, k0_counts, k0_offsets, k0_pairs, k0_coef, k0_flag, val_sol, val_obs, val_out, val_frames;
   DevBuf prof;
@@ -288,8 +293,8 @@ void csdo_dsqp_destroy(csdo_handle h) {
   (void)hipSetDevice(h->device);
   if (h->run_pending) (void)hipEventSynchronize(h->ev1);
   (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->agents, &h->worlds, &h->x0, &h->planes, &h->tstart, &h->obstacles, &h->rows_ws, &h->fac_ws,
-                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->order_d, &h->queues, &h->box_pts,
+  for (DevBuf* b : {&h->in_arena, &h->rows_ws, &h->fac_ws,
+                    &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->queues, &h->box_pts,
                     &h->box_obs, &h->box_out, &h->box_status, &h->prof, &h->k0_centres, &h->k0_counts, &h->k0_offsets,
                     &h->k0_pairs, &h->k0_coef, &h->k0_flag, &h->val_sol, &h->val_obs, &h->val_out, &h->val_frames})
     b->release();
@@ -368,18 +373,18 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
     }
   const double t1 = now_s();
   // stage everything in one page-locked arena (256-byte aligned slots), then one asynchronous copy per array
-  struct Item { DevBuf* buf; const void* src; size_t bytes; size_t off; };
-  Item items[] = {{&h->agents, hb.agents.data(), hb.agents.size() * sizeof(AgentDesc), 0},
-                  {&h->worlds, hb.worlds.data(), hb.worlds.size() * sizeof(WorldDesc), 0},
-                  {&h->x0, hb.x0.data(), hb.x0.size() * sizeof(double), 0},
-                  {&h->planes, hb.planes.data(), hb.planes.size() * sizeof(PlaneDev), 0},
-                  {&h->tstart, hb.tstart.data(), hb.tstart.size() * sizeof(int32_t), 0},
-                  {&h->obstacles, hb.obstacles.data(), hb.obstacles.size() * sizeof(double), 0},
-                  {&h->order_d, h->order.data(), h->order.size() * sizeof(int32_t), 0}};
+  struct Item { const void* src; size_t bytes; size_t off; };
+  Item items[] = {{hb.agents.data(), hb.agents.size() * sizeof(AgentDesc), 0},
+                  {hb.worlds.data(), hb.worlds.size() * sizeof(WorldDesc), 0},
+                  {hb.x0.data(), hb.x0.size() * sizeof(double), 0},
+                  {hb.planes.data(), hb.planes.size() * sizeof(PlaneDev), 0},
+                  {hb.tstart.data(), hb.tstart.size() * sizeof(int32_t), 0},
+                  {hb.obstacles.data(), hb.obstacles.size() * sizeof(double), 0},
+                  {h->order.data(), h->order.size() * sizeof(int32_t), 0}};
   size_t total = 0;
-  for (Item& it : items) {
-    it.off = total;
-    total += (it.bytes + 255) & ~(size_t)255;
+  for (int k = 0; k < 7; ++k) {
+    items[k].off = h->in_off[k] = total;
+    total += (items[k].bytes + 255) & ~(size_t)255;
   }
   if ((rc = h->stage_up.ensure(total)) != CSDO_OK) return rc;
   {
@@ -404,11 +409,8 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
     for (auto& t : pool) t.join();
   }
   const double t2 = now_s();
-  for (Item& it : items) {
-    if ((rc = it.buf->ensure(it.bytes)) != CSDO_OK) return rc;
-    if (it.bytes)
-      HIP_OK(hipMemcpyAsync(it.buf->p, (char*)h->stage_up.p + it.off, it.bytes, hipMemcpyHostToDevice, h->stream), CSDO_EDEVICE);
-  }
+  if ((rc = h->in_arena.ensure(total)) != CSDO_OK) return rc;
+  if (total) HIP_OK(hipMemcpyAsync(h->in_arena.p, h->stage_up.p, total, hipMemcpyHostToDevice, h->stream), CSDO_EDEVICE);
   h->t_pack = t1 - t0;
   h->t_stage = t2 - t1;
   if ((rc = h->queues.ensure(h->groups.size() * 64)) != CSDO_OK) return rc;   // one counter per group, a cache line apart
@@ -457,12 +459,13 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   if ((rc = h->legal.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
   if ((rc = h->ticks.ensure(Na * sizeof(int64_t))) != CSDO_OK) return rc;
   DeviceBatch& B = h->dev;
-  B.agents = (const AgentDesc*)h->agents.p;
-  B.worlds = (const WorldDesc*)h->worlds.p;
-  B.x0 = (const double*)h->x0.p;
-  B.planes = (const PlaneDev*)h->planes.p;
-  B.tstart = (const int32_t*)h->tstart.p;
-  B.obstacles = (const double*)h->obstacles.p;
+  const char* const in = (const char*)h->in_arena.p;
+  B.agents = (const AgentDesc*)(in + h->in_off[0]);
+  B.worlds = (const WorldDesc*)(in + h->in_off[1]);
+  B.x0 = (const double*)(in + h->in_off[2]);
+  B.planes = (const PlaneDev*)(in + h->in_off[3]);
+  B.tstart = (const int32_t*)(in + h->in_off[4]);
+  B.obstacles = (const double*)(in + h->in_off[5]);
   B.rows_ws = (double*)h->rows_ws.p;
   B.fac_ws = (double*)h->fac_ws.p;
   B.sol = (double*)h->sol.p;
@@ -472,7 +475,7 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   B.last_status = (int32_t*)h->stat.p;
   B.static_legal = (int32_t*)h->legal.p;
   B.agent_ticks = (int64_t*)h->ticks.p;
-  B.order = (const int32_t*)h->order_d.p;
+  B.order = (const int32_t*)(in + h->in_off[6]);
   B.n_agents = (int32_t)Na;
   B.prof = nullptr;
 #if defined(CSDO_PROFILE_PHASES)

@@ -185,7 +185,7 @@ class DsqpHandle:
             hc.run_async()
             if timing["first_launch"] is None:
                 timing["first_launch"] = time.perf_counter() - t0
-            timing["chunks"].append({"worlds": len(part), "bridge": tu - tb, "upload": tr - tu})
+            timing["chunks"].append({"worlds": len(part), "bridge": tu - tb, "upload": tr - tu, "upload_parts": hc.transfer_seconds()})
             inflight.append((hc, part))
         sols = [None] * n
         kernel_end = 0.0

@@ -27,4 +27,5 @@ for fr in sets.split(";"):
     print("%-24s total %.1f ms  first launch %.1f  kernels done %.1f  chunks %s" % (
         fr, best["total"] * 1e3, best["first_launch"] * 1e3, best["kernels_done"] * 1e3,
         [(c["worlds"], round(c["kernel"] * 1e3, 1)) for c in best["chunks"]]))
+    print("   upload of the chunks, ms:", [(round(c["upload"] * 1e3, 1), {k: round(v * 1e3, 1) for k, v in c.get("upload_parts", {}).items() if k in ("pack", "stage", "h2d")}) for c in best["chunks"]])
 h.close()

@@ -2035,9 +2035,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // lane and block).  Only the bounds, read once per iteration, are staged into LDS again: the factorisation's exchange
         // columns and the residual update's hand-over overwrite them (layout: Shm::lohi).
         LaneState& S = CSDO_LS(t);
-        if constexpr (MODE < 2) {
-          CSDO_FOR(i, 13, { SH(lohi, i, t) = WS(W_LO + i, t); });
-          CSDO_FOR(i, 9, { SH(lohi, 13 + i, t) = WS(W_HI + 7 + i, t); });
+        if constexpr (MODE < 2) {   // (loads first, then the stores: see the solver lanes' staging below)
+          double lo_[13], hi_[9];
+          CSDO_FOR(i, 13, { lo_[i] = WS(W_LO + i, t); });
+          CSDO_FOR(i, 9, { hi_[i] = WS(W_HI + 7 + i, t); });
+          CSDO_STAGE();
+          CSDO_FOR(i, 13, { SH(lohi, i, t) = lo_[i]; });
+          CSDO_FOR(i, 9, { SH(lohi, 13 + i, t) = hi_[i]; });
         }
         publish_rhs(S, t);
       }
@@ -2058,8 +2062,15 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(k, XER, { V.er[k] = FE(72 + k, tl); });
           {
             if (t < NtE) {
-              CSDO_FOR(k, XFX, { A2_LDS(k, t) = FE(72 + XER + k, t); });
-              if constexpr (CSDO_SINV_LDS != 0 && MODE == 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = WS(W_SINV + k, t); });
+              // (all loads first, then the LDS stores: written element by element - load, store, load ... - every load was waited
+              //  for before the next was issued: 27 trips to the workspace in a row at the head of every block)
+              double stg[XFX > 0 ? XFX : 1], sinv_[21];
+              CSDO_FOR(k, XFX, { stg[k] = FE(72 + XER + k, t); });
+              if constexpr (CSDO_SINV_LDS != 0 && MODE == 0) CSDO_FOR(k, 21, { sinv_[k] = WS(W_SINV + k, t); });
+              CSDO_STAGE();
+              CSDO_FOR(k, XFX, { A2_LDS(k, t) = stg[k]; });
+              if constexpr (CSDO_SINV_LDS != 0 && MODE == 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = sinv_[k]; });
+              (void)sinv_;
             }
           }
           V.ts0 = V.ts1 = 0;

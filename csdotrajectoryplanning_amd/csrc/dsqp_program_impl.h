@@ -992,20 +992,25 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       unsigned eq = 0, loose = 0;
+      // the scaled bounds go straight back to the workspace (the iterations read them from there / from LDS): held in the lane's
+      // registers until the publishing loop below they were spilled, and reloaded from scratch one by one in front of their stores
+      double lo_u[NROW], hi_u[NROW], e_u[NROW];
       CSDO_FOR(i, NROW, {
-        S.lo[i] = WS(W_LO + i, t);
-        S.hi[i] = WS(W_HI + i, t);
+        lo_u[i] = WS(W_LO + i, t);
+        hi_u[i] = WS(W_HI + i, t);
+        e_u[i] = SU(14 + i, t);
       });
       CSDO_FOR(i, NROW, {   // (every row: E = 1 and zero bounds where the row does not exist; classes only for those that do)
         {
-          const double Ei = SU(14 + i, t);
+          const double Ei = e_u[i];
           CD(C_E + i, t) = Ei;
-          S.lo[i] = Ei * S.lo[i];
-          S.hi[i] = Ei * S.hi[i];
+          const double lo_s = Ei * lo_u[i], hi_s = Ei * hi_u[i];
+          WS(W_LO + i, t) = lo_s;
+          WS(W_HI + i, t) = hi_s;
           // (without branches: as `if (..) loose |= bit; else if (..) eq |= bit;` the two masks became a two-element array in
           //  scratch, indexed by the outcome, read-modified-written once per row behind a full wait)
-          const bool is_loose = S.lo[i] < -OSQP_INFTY * MIN_SCALING && S.hi[i] > OSQP_INFTY * MIN_SCALING;
-          const bool is_eq = !is_loose && (S.hi[i] - S.lo[i] < RHO_TOL);
+          const bool is_loose = lo_s < -OSQP_INFTY * MIN_SCALING && hi_s > OSQP_INFTY * MIN_SCALING;
+          const bool is_eq = !is_loose && (hi_s - lo_s < RHO_TOL);
           loose |= is_loose ? (1u << i) : 0u;
           eq |= is_eq ? (1u << i) : 0u;
         }
@@ -1062,8 +1067,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         CSDO_FOR(s, 3, {
           if constexpr (row_col(i, s) >= 0) WS(W_C + 3 * i + s, t) = S.c[i][s];
         });
-        WS(W_LO + i, t) = S.lo[i];
-        WS(W_HI + i, t) = S.hi[i];
       });
       CSDO_FOR(i, 4, { WS(W_CN + i, t) = S.cn[i]; });
       WS(W_P + 0, t) = S.Pvv;
@@ -1690,10 +1693,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // the certificate test is false for every agent that has inter-vehicle rows; IEEE arithmetic reproduces it
         const double ninf = -INFINITY;
         for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {  // l = -inf, u finite
-          const double d = osqp_max(ROW(r, R_DY), 0.0);
+          const double dy_r = ROW(r, R_DY), e_r = ROW(r, R_E), u_r = ROW(r, R_U);   // (all three in flight before the store)
+          const double d = osqp_max(dy_r, 0.0);
           ROW(r, R_DY) = d;
-          nmax = dmax(nmax, fabs(ROW(r, R_E) * d));
-          acc += ROW(r, R_U) * osqp_max(d, 0.0) + ninf * osqp_min(d, 0.0);
+          nmax = dmax(nmax, fabs(e_r * d));
+          acc += u_r * osqp_max(d, 0.0) + ninf * osqp_min(d, 0.0);
         }
         const double part[2] = {nmax, acc};
         red_put<2>(sh, t, part);

@@ -138,7 +138,11 @@ __device__ __forceinline__ double csdo_dpp_f64(const double v) {   // (bound_ctr
     }                                                                    \
   } while (0)
 #else
+#if defined(CSDO_ASM_MARKS)
+#define CSDO_PHASE(k) asm volatile("; CSDO_MARK phase_" #k)
+#else
 #define CSDO_PHASE(k) ((void)0)
+#endif
 #endif
 #elif defined(CSDO_LANE_MODE_SERIAL)
 #define csdo_keep(v) (v)

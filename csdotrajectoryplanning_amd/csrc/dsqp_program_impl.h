@@ -155,7 +155,11 @@ struct FactorProf {   // diagnostic build: the caller's phase timers (slots 16..
   } while (0)
 #else
 struct FactorProf {};
+#if defined(CSDO_ASM_MARKS)   // analysis builds only (scripts/asm_serial_loads.py): phase boundaries as comments in the assembly
+#define CSDO_FPHASE(k) asm volatile("; CSDO_MARK fphase_" #k)
+#else
 #define CSDO_FPHASE(k) ((void)0)
+#endif
 #endif
 template <int ROLE, int MODE>
 CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t rcap_in, const int32_t* tstart_in,
@@ -500,14 +504,24 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           if ((t + h) < Nt) {
             CSDO_FOR(k, 21, { A[k] -= XC(21 + k, t); });
             const bool has_rr = (t + 2 * h) < Nt;
-            CSDO_FOR(k, 36, { FR(k, t) = has_rr ? XC(42 + k, t) : 0.0; });
+            // (one branch and the 36 reads in flight: as `has_rr ? read : 0.0` per element it was a branch, an LDS round trip and - for
+            //  the zero, a spilled constant - a scratch reload in front of every one of the 36 stores)
+            if (has_rr) {
+              CSDO_FOR(k, 36, { FR(k, t) = XC(42 + k, t); });
+            } else {
+              CSDO_FOR(k, 36, { FR(k, t) = 0.0; });
+            }
           }
         } else {
           if (t >= h) CSDO_FOR(k, 21, { A[k] -= SX(21 + k, t - h); });
           if ((t + h) < Nt) {
             CSDO_FOR(k, 21, { A[k] -= SX(k, t + h); });
             const bool has_rr = (t + 2 * h) < Nt;
-            CSDO_FOR(k, 36, { FR(k, t) = has_rr ? SX(42 + k, t + h) : 0.0; });
+            if (has_rr) {
+              CSDO_FOR(k, 36, { FR(k, t) = SX(42 + k, t + h); });
+            } else {
+              CSDO_FOR(k, 36, { FR(k, t) = 0.0; });
+            }
           }
         }
         CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
@@ -680,7 +694,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #define CSDO_XT_RESET() ((void)0)
 #define CSDO_XT(k) ((void)0)
 #define CSDO_SUB_RESET() ((void)0)
+#if defined(CSDO_ASM_MARKS)
+#define CSDO_SUB(k) asm volatile("; CSDO_MARK sub_" #k)
+#else
 #define CSDO_SUB(k) ((void)0)
+#endif
 #endif
 
 #define ROW(r, f) (rows + (int64_t)(f) * rcap)[(unsigned)(r)]

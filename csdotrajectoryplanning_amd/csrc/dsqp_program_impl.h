@@ -181,39 +181,54 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   }
   CSDO_SYNC();
   CSDO_SLANES(t) {
-    const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
+    // One batch of loads for everything the two blocks need of the home rows (27 coefficients, 4 coupling coefficients, the three
+    // objective terms, the masks), and no per-row existence test: a row that does not exist at this t has zero coefficients
+    // (assemble_home_rows) and its mask bits are clear, so it adds rho * 0 * 0 = +0.0 to sums that are never -0.0 - the same
+    // bits.  (Row by row behind `if (act & bit)` every row's coefficients were a trip to the workspace of their own.)
+    const unsigned eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
     const int ncols = (t < Nm) ? 6 : 4;
+    double cc[NROW][3], cnn[4], pp[3];
+    CSDO_FOR(i, NROW, {
+      CSDO_FOR(s1, 3, {
+        if constexpr (row_col(i, s1) >= 0) cc[i][s1] = WS(W_C + 3 * i + s1, t);
+        else cc[i][s1] = 0.0;
+      });
+    });
+    CSDO_FOR(i, 4, { cnn[i] = WS(W_CN + i, t); });
+    CSDO_FOR(k, 3, { pp[k] = WS(W_P + k, t); });
     {   // diagonal block
       double A[21];
       CSDO_FOR(k, 21, { A[k] = 0.0; });
       CSDO_FOR(j, 6, { A[sym(j, j)] = (j < ncols) ? sigma : 1.0; });
-      A[sym(4, 4)] += WS(W_P + 0, t);
-      A[sym(5, 5)] += WS(W_P + 1, t);
+      A[sym(4, 4)] += pp[0];
+      A[sym(5, 5)] += pp[1];
       if (t > 0) CSDO_FOR(k, 4, { A[sym(k, k)] += SH(carry, k, t - 1); });
       CSDO_FOR(i, NROW, {
-        if (act & (1u << i)) {
-          const double rh = rho_of_masks(eqm, lom, i, rho_now);
-          double ci[3] = {0, 0, 0};
-          CSDO_FOR(s1, 3, {
-            if constexpr (row_col(i, s1) >= 0) ci[s1] = WS(W_C + 3 * i + s1, t);
-          });
-          CSDO_FOR(s1, 3, {
-            if constexpr (row_col(i, s1) >= 0) {
-              const double rc = rh * ci[s1];
-              CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, ci[s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
-            }
-          });
-        }
+        const double rh = rho_of_masks(eqm, lom, i, rho_now);
+        CSDO_FOR(s1, 3, {
+          if constexpr (row_col(i, s1) >= 0) {
+            const double rc = rh * cc[i][s1];
+            CSDO_FOR(s2, s1 + 1, { A[sym(row_col(i, s1), row_col(i, s2))] = fma(rc, cc[i][s2], A[sym(row_col(i, s1), row_col(i, s2))]); });
+          }
+        });
       });
-      for (int r = 4 * tstart[t]; r < 4 * tstart[t + 1]; ++r) {
-        const double a = ROW(r, R_CA), bb = ROW(r, R_CB), cy = ROW(r, R_CY);
-        // inter rows have l = -inf and finite u: never loose, never equality (u - l = inf)
-        A[sym(0, 0)] = fma(rho_now * a, a, A[sym(0, 0)]);
-        A[sym(1, 0)] = fma(rho_now * bb, a, A[sym(1, 0)]);
-        A[sym(1, 1)] = fma(rho_now * bb, bb, A[sym(1, 1)]);
-        A[sym(2, 0)] = fma(rho_now * cy, a, A[sym(2, 0)]);
-        A[sym(2, 1)] = fma(rho_now * cy, bb, A[sym(2, 1)]);
-        A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
+      for (int pl_ = tstart[t]; pl_ < tstart[t + 1]; ++pl_) {   // a plane's four rows: their twelve coefficients in flight at once
+        double a4[4], b4[4], c4[4];
+        CSDO_FOR(q, 4, {
+          a4[q] = ROW(4 * pl_ + q, R_CA);
+          b4[q] = ROW(4 * pl_ + q, R_CB);
+          c4[q] = ROW(4 * pl_ + q, R_CY);
+        });
+        CSDO_FOR(q, 4, {
+          const double a = a4[q], bb = b4[q], cy = c4[q];
+          // inter rows have l = -inf and finite u: never loose, never equality (u - l = inf)
+          A[sym(0, 0)] = fma(rho_now * a, a, A[sym(0, 0)]);
+          A[sym(1, 0)] = fma(rho_now * bb, a, A[sym(1, 0)]);
+          A[sym(1, 1)] = fma(rho_now * bb, bb, A[sym(1, 1)]);
+          A[sym(2, 0)] = fma(rho_now * cy, a, A[sym(2, 0)]);
+          A[sym(2, 1)] = fma(rho_now * cy, bb, A[sym(2, 1)]);
+          A[sym(2, 2)] = fma(rho_now * cy, cy, A[sym(2, 2)]);
+        });
       }
       CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
     }
@@ -222,18 +237,16 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       double R[36];
       CSDO_FOR(k, 36, { R[k] = 0.0; });
       CSDO_FOR(i, 4, {
-        if (act & (1u << i)) {
-          const double rh = rho_of_masks(eqm, lom, i, rho_now);
-          const double cni = WS(W_CN + i, t);
-          CSDO_FOR(s1, 3, {
-            if constexpr (row_col(i, s1) >= 0) {
-              const double rc = rh * WS(W_C + 3 * i + s1, t);
-              R[i * 6 + row_col(i, s1)] = fma(rc, cni, R[i * 6 + row_col(i, s1)]);
-            }
-          });
-        }
+        const double rh = rho_of_masks(eqm, lom, i, rho_now);
+        const double cni = cnn[i];
+        CSDO_FOR(s1, 3, {
+          if constexpr (row_col(i, s1) >= 0) {
+            const double rc = rh * cc[i][s1];
+            R[i * 6 + row_col(i, s1)] = fma(rc, cni, R[i * 6 + row_col(i, s1)]);
+          }
+        });
       });
-      R[4 * 6 + 4] += WS(W_P + 2, t);
+      R[4 * 6 + 4] += pp[2];
       const bool has_r = (t + 1) < Nt;
       CSDO_FOR(k, 36, { FR(k, t) = has_r ? R[k] : 0.0; });
     }

@@ -312,10 +312,15 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                   PF_L(c * 6 + r, t) = tc[r];
                   if (!has_r) PF_R(c * 6 + r, t) = (c >= 3) ? tc[r] : 0.0;
                 });
-                CSDO_FOR(a_, 6, {            // column c of U_l = Rl' T (lower triangle)
-                  double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(FR(k * 6 + a_, base), tc[k], a); });
-                  if (a_ >= c) XC(21 + a_ * (a_ + 1) / 2 + c, base) = a;
+                CSDO_FOR(ah, 2, {            // column c of U_l = Rl' T (lower triangle), three rows' operands per batch of loads
+                  double rl[18];
+                  CSDO_FOR(k, 6, { CSDO_FOR(a3, 3, { rl[k * 3 + a3] = FR(k * 6 + 3 * ah + a3, base); }); });
+                  CSDO_FOR(a3, 3, {
+                    constexpr int a_ = 3 * ah + a3;
+                    double a = 0.0;
+                    CSDO_FOR(k, 6, { a = fma(rl[k * 3 + a3], tc[k], a); });
+                    if (a_ >= c) XC(21 + a_ * (a_ + 1) / 2 + c, base) = a;
+                  });
                 });
               } while (__builtin_expect(++cc < per, 0));
             }
@@ -326,10 +331,15 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 double tc[6], rrc[6], vc[6];
                 CSDO_FOR(k, 6, { tc[k] = XC(k * 6 + c, t); });
                 CSDO_FOR(k, 6, { rrc[k] = FR(c * 6 + k, t); });
-                CSDO_FOR(a_, 6, {            // column c of the new coupling (right node <- left node) = -Rr T
-                  double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(FR(a_ * 6 + k, t), tc[k], a); });
-                  XC(42 + a_ * 6 + c, base) = -a;
+                CSDO_FOR(ah, 2, {            // column c of the new coupling (right node <- left node) = -Rr T, three rows per batch
+                  double rr[18];
+                  CSDO_FOR(k, 18, { rr[k] = FR(18 * ah + k, t); });
+                  CSDO_FOR(a3, 3, {
+                    constexpr int a_ = 3 * ah + a3;
+                    double a = 0.0;
+                    CSDO_FOR(k, 6, { a = fma(rr[a3 * 6 + k], tc[k], a); });
+                    XC(42 + a_ * 6 + c, base) = -a;
+                  });
                 });
                 CSDO_FOR(r, 6, {             // column c of V = Sinv Rr'; F_r = E_r Sinv = V'
                   double a = 0.0;
@@ -337,10 +347,15 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                   vc[r] = a;
                 });
                 CSDO_FOR(r, 6, { XC(r * 6 + c, t) = vc[r]; });
-                CSDO_FOR(a_, 6, {            // column c of U_r = Rr V (lower triangle)
-                  double a = 0.0;
-                  CSDO_FOR(k, 6, { a = fma(FR(a_ * 6 + k, t), vc[k], a); });
-                  if (a_ >= c) XC(a_ * (a_ + 1) / 2 + c, t + h) = a;
+                CSDO_FOR(ah, 2, {            // column c of U_r = Rr V (lower triangle)
+                  double rr[18];
+                  CSDO_FOR(k, 18, { rr[k] = FR(18 * ah + k, t); });
+                  CSDO_FOR(a3, 3, {
+                    constexpr int a_ = 3 * ah + a3;
+                    double a = 0.0;
+                    CSDO_FOR(k, 6, { a = fma(rr[a3 * 6 + k], vc[k], a); });
+                    if (a_ >= c) XC(a_ * (a_ + 1) / 2 + c, t + h) = a;
+                  });
                 });
               } while (__builtin_expect(++cc < per, 0));
             }

@@ -331,26 +331,22 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
                 double tc[6], rrc[6], vc[6];
                 CSDO_FOR(k, 6, { tc[k] = XC(k * 6 + c, t); });
                 CSDO_FOR(k, 6, { rrc[k] = FR(c * 6 + k, t); });
-                CSDO_FOR(ah, 2, {            // column c of the new coupling (right node <- left node) = -Rr T, three rows per batch
-                  double rr[18];
-                  CSDO_FOR(k, 18, { rr[k] = FR(18 * ah + k, t); });
-                  CSDO_FOR(a3, 3, {
-                    constexpr int a_ = 3 * ah + a3;
-                    double a = 0.0;
-                    CSDO_FOR(k, 6, { a = fma(rr[a3 * 6 + k], tc[k], a); });
-                    XC(42 + a_ * 6 + c, base) = -a;
-                  });
-                });
                 CSDO_FOR(r, 6, {             // column c of V = Sinv Rr'; F_r = E_r Sinv = V'
                   double a = 0.0;
                   CSDO_FOR(k, 6, { a = fma(SV(sym(r, k)), rrc[k], a); });
                   vc[r] = a;
                 });
                 CSDO_FOR(r, 6, { XC(r * 6 + c, t) = vc[r]; });
-                CSDO_FOR(ah, 2, {            // column c of U_r = Rr V (lower triangle)
+                CSDO_FOR(ah, 2, {            // three rows of Rr per batch of loads, used by both products:
                   double rr[18];
                   CSDO_FOR(k, 18, { rr[k] = FR(18 * ah + k, t); });
-                  CSDO_FOR(a3, 3, {
+                  CSDO_FOR(a3, 3, {          // column c of the new coupling (right node <- left node) = -Rr T
+                    constexpr int a_ = 3 * ah + a3;
+                    double a = 0.0;
+                    CSDO_FOR(k, 6, { a = fma(rr[a3 * 6 + k], tc[k], a); });
+                    XC(42 + a_ * 6 + c, base) = -a;
+                  });
+                  CSDO_FOR(a3, 3, {          // column c of U_r = Rr V (lower triangle)
                     constexpr int a_ = 3 * ah + a3;
                     double a = 0.0;
                     CSDO_FOR(k, 6, { a = fma(rr[a3 * 6 + k], vc[k], a); });

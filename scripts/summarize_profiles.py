@@ -48,7 +48,9 @@ for f in find("trace/**/*kernel_trace.csv"):
         t0 = disp[0][1]
         steps, cur_end = [], None      # a step = dispatches of any agent kernel that overlap in time
         for name, a, b in disp:
-            if cur_end is None or a > cur_end:
+            # (a group's second launch that finds its queue empty is a dispatch of a few microseconds, possibly behind the end of
+            #  every other kernel of its step: it belongs to that step, it is not a step)
+            if cur_end is None or (a > cur_end and (b - a) > 200000):
                 steps.append([])
                 cur_end = b
             steps[-1].append((name, a, b))

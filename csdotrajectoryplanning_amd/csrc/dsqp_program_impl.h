@@ -269,21 +269,25 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       // Schur complements are DELIVERED into the columns of the two surviving neighbours: fields 0..20 <- U_r of the left
       // neighbour, 21..41 <- U_l of the right neighbour, 42..77 <- the new coupling from the right neighbour.  (Through the
       // workspace the absorption alone was 19 k cycles per level: the workspaces of the 32 agents of an XCD do not fit its L2.)
-      CSDO_SLANES(t) {
-        if ((t & m2) == h) {
-          double Sinv[21];
-          {
-            double Ain[21];
-            CSDO_FOR(k, 21, { Ain[k] = FA(k, t); });
-            spd_inverse6(Ain, Sinv);
+      // (levels h >= 2: the node inverted its pivot block at the end of the previous level's absorption, where the block was in
+      //  its registers - no second trip to the workspace for it, one barrier less per level)
+      if (h == 1) {
+        CSDO_SLANES(t) {
+          if ((t & m2) == h) {
+            double Sinv[21];
+            {
+              double Ain[21];
+              CSDO_FOR(k, 21, { Ain[k] = FA(k, t); });
+              spd_inverse6(Ain, Sinv);
+            }
+            CSDO_FOR(k, 21, {
+              WS(W_SINV + k, t) = Sinv[k];
+              XC(36 + k, t) = Sinv[k];
+            });
           }
-          CSDO_FOR(k, 21, {
-            WS(W_SINV + k, t) = Sinv[k];
-            XC(36 + k, t) = Sinv[k];
-          });
         }
+        CSDO_SYNC();
       }
-      CSDO_SYNC();
       const int G = (h == 1) ? 2 : ((h == 2) ? 3 : 6), per = 6 / G;
       CSDO_STHREADS(l0, nthr) {
         // The loops of this stage are marked cold: by their nesting depth alone the register allocator ranks them above the ADMM
@@ -551,6 +555,17 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           }
         }
         CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
+        if constexpr (MODE == 0) {   // eliminated at the next level: the pivot inverse now, while the block is here (see the head of the level)
+          const int h2 = 2 * h;
+          if (h2 < h_tail && (t & (2 * h2 - 1)) == h2) {
+            double Sinv[21];
+            spd_inverse6(A, Sinv);
+            CSDO_FOR(k, 21, {
+              WS(W_SINV + k, t) = Sinv[k];
+              XC(36 + k, t) = Sinv[k];
+            });
+          }
+        }
       }
     }
     CSDO_SYNC();

@@ -233,6 +233,16 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
         });
       }
       CSDO_FOR(k, 21, { FA(k, t) = A[k]; });
+      if constexpr (MODE == 0) {   // eliminated at level 1: the pivot inverse now (see the head of the level loop)
+        if (h_tail > 1 && (t & 1)) {
+          double Sinv[21];
+          spd_inverse6(A, Sinv);
+          CSDO_FOR(k, 21, {
+            WS(W_SINV + k, t) = Sinv[k];
+            sh.vec[(size_t)(36 + k) * csdo_opaque_s(sh.stride) + (unsigned)t] = Sinv[k];   // XC(36 + k, t)
+          });
+        }
+      }
     }
     CSDO_STAGE();
     {   // coupling to t+1: kinematic rows (rho c_i c_next_i at [i][col]) and the v_t v_{t+1} term of P
@@ -269,25 +279,8 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       // Schur complements are DELIVERED into the columns of the two surviving neighbours: fields 0..20 <- U_r of the left
       // neighbour, 21..41 <- U_l of the right neighbour, 42..77 <- the new coupling from the right neighbour.  (Through the
       // workspace the absorption alone was 19 k cycles per level: the workspaces of the 32 agents of an XCD do not fit its L2.)
-      // (levels h >= 2: the node inverted its pivot block at the end of the previous level's absorption, where the block was in
-      //  its registers - no second trip to the workspace for it, one barrier less per level)
-      if (h == 1) {
-        CSDO_SLANES(t) {
-          if ((t & m2) == h) {
-            double Sinv[21];
-            {
-              double Ain[21];
-              CSDO_FOR(k, 21, { Ain[k] = FA(k, t); });
-              spd_inverse6(Ain, Sinv);
-            }
-            CSDO_FOR(k, 21, {
-              WS(W_SINV + k, t) = Sinv[k];
-              XC(36 + k, t) = Sinv[k];
-            });
-          }
-        }
-        CSDO_SYNC();
-      }
+      // (the node inverted its pivot block where the block was last in its registers: at the end of the assembly - level 1 - or of
+      //  the previous level's absorption; no second trip to the workspace for it, one barrier less per level)
       const int G = (h == 1) ? 2 : ((h == 2) ? 3 : 6), per = 6 / G;
       CSDO_STHREADS(l0, nthr) {
         // The loops of this stage are marked cold: by their nesting depth alone the register allocator ranks them above the ADMM

@@ -99,28 +99,8 @@ class DsqpHandle:
         import time
         n = len(items)
         idx = list(range(n)) if order is None else [int(i) for i in order]
-        fr = [f for f in fractions if f > 0]
-        fr = fr[-min(len(fr), n, 4):]                      # at most four batches in flight (four streams), never an empty chunk
-        cuts = [0]
-        tot = float(sum(fr))
-        acc = 0.0
-        for c, f in enumerate(fr):
-            acc += f
-            hi = n if c == len(fr) - 1 else max(cuts[-1] + 1, min(n - (len(fr) - 1 - c), int(round(n * acc / tot))))
-            cuts.append(hi)
-        # The first chunk has to fill the GPU by itself (one workgroup per CU: about 230 agents), else the CUs it leaves idle are
-        # lost until the second chunk arrives; and a job that such a first chunk takes a fifth of is split in two, not three
-        # (100-vehicle worlds, 12 of them: 1 + 3 + 8 worlds 70.7 ms, 3 + 3 + 6 72.1, 3 + 9 66.6, one launch 67.1).
-        na = np.cumsum([len(items[i][2]) - 1 for i in idx])
-        fill = int(np.searchsorted(na, min_first_agents)) + 1
-        if len(cuts) > 2 and cuts[1] < fill:
-            if fill >= n:
-                cuts = [0, n]
-            elif fill >= 0.2 * n:
-                cuts = [0, fill, n]
-            else:
-                cuts = [0, fill] + [max(c_, fill + k_ + 1) for k_, c_ in enumerate(cuts[2:-1])] + [n]
-            fr = fr[:len(cuts) - 1]
+        cuts = stream_cuts([len(items[i][2]) - 1 for i in idx], fractions, min_first_agents)
+        fr = [None] * (len(cuts) - 1)
         t0 = time.perf_counter()
         if single_launch_if_mixed:
             # The horizon of a world is known from its coarse paths (sqp/inter_agent_cons.cc:320-325: the longest path, num_interpolation
@@ -353,6 +333,34 @@ def _marshal_paths(items):
         st_p[k], ac_p[k], po_p[k], g_p[k] = abi.as_double_p(st), abi.as_int32_p(ac), abi.as_int32_p(po), abi.as_double_p(G)
         na[k] = len(po) - 1
     return keep, st_p, ac_p, po_p, na, g_p
+
+
+def stream_cuts(agents_per_world, fractions=(0.08, 0.27, 0.65), min_first_agents=230):
+    """Chunk boundaries of a streamed DO phase over len(agents_per_world) worlds (DsqpHandle.do_phase_stream): growing chunks by
+    `fractions` (at most four, never an empty one), the first one enlarged until it holds `min_first_agents` agents - it has to fill
+    the GPU by itself (one workgroup per CU), else the CUs it leaves idle are lost until the second chunk arrives -, and a job that
+    such a first chunk takes a fifth of is split in two, not three (100-vehicle worlds, 12 of them: 1 + 3 + 8 worlds 70.7 ms,
+    3 + 3 + 6 72.1, 3 + 9 66.6, one launch 67.1).  Returns [0, c1, ..., n]."""
+    n = len(agents_per_world)
+    fr = [f for f in fractions if f > 0]
+    fr = fr[-min(len(fr), n, 4):]                      # at most four batches in flight (four streams), never an empty chunk
+    cuts = [0]
+    tot = float(sum(fr))
+    acc = 0.0
+    for c, f in enumerate(fr):
+        acc += f
+        hi = n if c == len(fr) - 1 else max(cuts[-1] + 1, min(n - (len(fr) - 1 - c), int(round(n * acc / tot))))
+        cuts.append(hi)
+    na = np.cumsum(agents_per_world)
+    fill = int(np.searchsorted(na, min_first_agents)) + 1
+    if len(cuts) > 2 and cuts[1] < fill:
+        if fill >= n:
+            cuts = [0, n]
+        elif fill >= 0.2 * n:
+            cuts = [0, fill, n]
+        else:
+            cuts = [0, fill] + [max(c_, fill + k_ + 1) for k_, c_ in enumerate(cuts[2:-1])] + [n]
+    return cuts
 
 
 def interpolate_and_planes_batch_host(items, veh, parm):

@@ -167,3 +167,20 @@ def test_map100_set_shards_by_the_launchers_work_estimate():
     assert loads.max() <= 1.02 * loads.mean()
     # estimates of a sub-batch equal the slice of the whole batch's (per agent, no cross-talk)
     assert np.array_equal(estimate_work(worlds[3:5]), est[150:250])
+
+
+def test_stream_cuts_of_the_streamed_do_phase():
+    """Chunking rule of DsqpHandle.do_phase_stream (host logic, no GPU): growing chunks, never an empty one, the first one large
+    enough to fill the GPU, two chunks instead of three when that first chunk is a fifth of the job."""
+    from csdotrajectoryplanning_amd.solver import stream_cuts
+    assert stream_cuts([50] * 60) == [0, 5, 21, 60]                 # the map100 set: 250 agents fill the 256 CUs
+    assert stream_cuts([100] * 12) == [0, 3, 12]                    # 100-vehicle worlds: 1 + 3 + 8 would leave the GPU two thirds empty
+    assert stream_cuts([25] * 60) == [0, 10, 21, 60]
+    assert stream_cuts([25] * 7) == [0, 7] and stream_cuts([50]) == [0, 1]
+    assert stream_cuts([25] * 7, min_first_agents=0) == [0, 1, 2, 7]
+    assert stream_cuts([300] * 3) == [0, 1, 2, 3]
+    for n in range(1, 40):
+        for na in (1, 10, 50, 300):
+            for fr in ((0.08, 0.27, 0.65), (0.5, 0.5), (1.0,), (0.1, 0.2, 0.3, 0.4), (0.05, 0.05, 0.1, 0.2, 0.6)):
+                c = stream_cuts([na] * n, fr)
+                assert c[0] == 0 and c[-1] == n and all(b > a for a, b in zip(c, c[1:])) and len(c) <= 5, (n, na, fr, c)

@@ -1362,6 +1362,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // lanes only form second halves, which start from 0.
       auto sinv_times = [&](const int node, const double (&bb)[6], double (&w6)[6]) __attribute__((always_inline)) {
         const int nd = csdo_keep(node);   // (the LDS address formed here: hoisted out of the iterations it is spilled)
+        if constexpr (MODE == 0) {
+          // the 21 packed entries in eleven 16-byte reads, once (row by row through sym() they were 36 8-byte reads in two halves)
+          double s21[21];
+          CSDO_FOR(k, 21, { s21[k] = SINV(k, nd); });
+          CSDO_FOR(r, 6, {
+            const double s01 = fma(s21[sym(r, 1)], bb[1], s21[sym(r, 0)] * bb[0]);
+            const double s23 = fma(s21[sym(r, 3)], bb[3], s21[sym(r, 2)] * bb[2]);
+            const double s45 = fma(s21[sym(r, 5)], bb[5], s21[sym(r, 4)] * bb[4]);
+            w6[r] = (s01 + s23) + s45;
+          });
+        } else
         CSDO_FOR(half, 2, {
           double sv[3][6];
           CSDO_FOR(r3, 3, {

@@ -68,6 +68,7 @@ def lib():
         L.csdo_bridge_free.restype = None
         L.csdo_generate_boxes.argtypes = [H, abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                           C.c_double, C.POINTER(abi.Vehicle), abi.c_double_p, abi.c_int32_p]
+        L.csdo_math_eval.argtypes = [H, C.c_int32, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_int32]
         L.csdo_vehicle_default.argtypes = [C.POINTER(abi.Vehicle)]
         L.csdo_vehicle_default.restype = None
         L.csdo_qp_parm_default.argtypes = [C.POINTER(abi.Vehicle), C.POINTER(abi.QpParm)]

@@ -76,6 +76,7 @@ inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   s.rv = v.rv;
   s.WB = v.WB;
   s.r_turn = v.r;
+  s.steer_max = std::atan(v.WB / v.r);
   s.r_trust = p.r_trust;
   s.max_omega = p.max_omega;
   s.max_v = p.max_v;

@@ -693,6 +693,25 @@ int csdo_generate_boxes(csdo_handle h, const double* points_xy, int32_t n, const
   return CSDO_OK;
 }
 
+int csdo_math_eval(csdo_handle h, int32_t fn, const double* a, const double* b, double* out, int32_t n) {
+  if (!h || !a || !out || n < 0 || fn < 0 || fn > 3 || (fn == 3 && !b)) return CSDO_EINVAL;
+  if (n == 0) return CSDO_OK;
+  HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
+  int rc;
+  const size_t bytes = (size_t)n * sizeof(double);
+  if ((rc = h->box_pts.ensure(2 * bytes)) != CSDO_OK) return rc;
+  if ((rc = h->box_out.ensure(bytes)) != CSDO_OK) return rc;
+  hipStream_t s = h->stream;
+  double* da = (double*)h->box_pts.p;
+  double* db = da + n;
+  HIP_OK(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  HIP_OK(hipMemcpyAsync(db, fn == 3 ? b : a, bytes, hipMemcpyHostToDevice, s), CSDO_EDEVICE);
+  if (launch_math_probe(fn, da, db, (double*)h->box_out.p, n, s) != hipSuccess) return CSDO_EDEVICE;
+  HIP_OK(hipMemcpyAsync(out, h->box_out.p, bytes, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+  HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
+  return CSDO_OK;
+}
+
 int csdo_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                     const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out) {
   return bridge_preprocess(states, actions, path_off, Na, goals, veh, parm, out);

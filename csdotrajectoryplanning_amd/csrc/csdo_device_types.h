@@ -38,6 +38,7 @@ struct PlaneDev {  // mirrors csdo_plane
 struct SolverParams {
   // vehicle (float-rounded values widened to double; common/motion_planning.h:12-49 of the reference)
   double f2x, r2x, rv, WB, r_turn;
+  double steer_max;   // atan(WB / r_turn) (sqp/dsqp_solver.cc:1178), a constant of the batch: formed once by the host
   // QpParm (sqp/common.h:39-52)
   double r_trust, max_omega, max_v, delta_solution_threshold, dt;
   int32_t max_iter, osqp_max_iter, fixed_corridor, adaptive_rho_interval;

@@ -34,6 +34,23 @@ __global__ void box_kernel(const double* __restrict__ pts, int n, const double* 
   boxes[4 * i + 3] = b.y_max;
 }
 
+// the program's sin / cos / tan / atan2 (csdo_math.h) on arbitrary arguments: what csdo_math_eval runs (a diagnostic entry - the
+// parity tests compare its bits with the host build of the same header)
+__global__ void math_probe_kernel(int fn, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  double r;
+  if (fn == 0) r = sincos_of(a[i]).s;
+  else if (fn == 1) r = sincos_of(a[i]).c;
+  else if (fn == 2) r = tan_of(a[i]);
+  else r = atan2_of(a[i], b[i]);
+  out[i] = r;
+}
+hipError_t launch_math_probe(int fn, const double* a, const double* b, double* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, a, b, out, n);
+  return hipGetLastError();
+}
+
 size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) {
   const int st = (nt + 1) & ~1;
   // exchange vectors vec, pr, rhs, carry (6 each) + bounds of the home rows 22 (the t -> t-1 hand-over aliases them) +

@@ -28,4 +28,5 @@ int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds);
 hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream);
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,
                         double* boxes, int* status, hipStream_t stream);
+hipError_t launch_math_probe(int fn, const double* a, const double* b, double* out, int n, hipStream_t stream);
 }  // namespace csdo

@@ -45,7 +45,8 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
   const double dt = P.dt, WB = P.WB;
   const double yaw = CD(C_SOL0 + 2, t), st = CD(C_SOL0 + 3, t), v = CD(C_SOL0 + 4, t);
   const double xt = CD(C_XT, t), yt = CD(C_YT, t), yawt = CD(C_YAWT, t);
-  const double sy = sin(yaw), cy = cos(yaw);
+  const SinCos scy_ = sincos_of(yaw);
+  const double sy = scy_.s, cy = scy_.c;
   CSDO_FOR(i, NROW, {
     CSDO_FOR(s, 3, { S.c[i][s] = 0.0; });
     S.lo[i] = 0.0;
@@ -55,7 +56,7 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
   unsigned act = 0x0780u | 0x1800u | 0x8000u;  // corridor, trust, steer rows exist at every t
   if (t < Nm) {
     act |= ROWS_KIN | ROWS_CTRL;
-    const double cst = cos(st);
+    const double cst = sincos_of(st).c;
     const double cst2 = cst * cst;  // (steer.cos()).pow(2)
     // x-dyn
     S.c[0][0] = 1.0;
@@ -72,7 +73,7 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
     // yaw-dyn
     S.c[2][0] = 1.0;
     S.c[2][1] = (dt / WB * v) / cst2;
-    S.c[2][2] = dt / WB * tan(st);
+    S.c[2][2] = dt / WB * tan_of(st);
     S.cn[2] = -1.0;
     S.lo[2] = S.hi[2] = -(-dt * (st * v / WB / cst2));
     // steer-dyn
@@ -114,7 +115,7 @@ CSDO_FN void assemble_home_rows(LaneState& S, const Shm& sh, int t, int Nt, cons
   S.c[11][0] = 1.0; S.lo[11] = -P.r_trust + xt; S.hi[11] = P.r_trust + xt;
   S.c[12][0] = 1.0; S.lo[12] = -P.r_trust + yt; S.hi[12] = P.r_trust + yt;
   // steer box
-  const double steer_max = atan(P.WB / P.r_turn);
+  const double steer_max = P.steer_max;   // atan(WB / r), formed by the host (batch_pack.h: make_params)
   S.c[15][0] = 1.0; S.lo[15] = -steer_max; S.hi[15] = steer_max;
   S.act = act;
   // objective: first-difference Laplacian on v (Neumann ends), identity on w
@@ -780,7 +781,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   // State's disc centres are float members (motion_planning.h:115-118,229-230): round through float here.
   CSDO_SLANES(t) {  // rear disc on the solver lane
     const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
-    const double xr = (double)(float)(px + P.r2x * cos(pyaw)), yr = (double)(float)(py + P.r2x * sin(pyaw));
+    const SinCos scp_ = sincos_of(pyaw);
+    const double spy = scp_.s, cpy = scp_.c;
+    const double xr = (double)(float)(px + P.r2x * cpy), yr = (double)(float)(py + P.r2x * spy);
     BoxD br;
     const int sr = make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
     CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
@@ -790,7 +793,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   double my_flag = 0.0;
   CSDO_LANES(t) {   // front disc on the row lane
     const double px = CD(C_SOL0 + 0, t), py = CD(C_SOL0 + 1, t), pyaw = CD(C_SOL0 + 2, t);
-    const double xf = (double)(float)(px + P.f2x * cos(pyaw)), yf = (double)(float)(py + P.f2x * sin(pyaw));
+    const SinCos scp_ = sincos_of(pyaw);
+    const double spy = scp_.s, cpy = scp_.c;
+    const double xf = (double)(float)(px + P.f2x * cpy), yf = (double)(float)(py + P.f2x * spy);
     BoxD bf;
     const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
     CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
@@ -2465,21 +2470,22 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
       CSDO_SYNC();
       CSDO_LANES(t) {
-        LaneState& S = CSDO_LS(t);
         double p[6] = {0, 0, 0, 0, 0, 0};
         const double x = CD(C_SOL + 0, t), y = CD(C_SOL + 1, t), yaw = CD(C_SOL + 2, t), stv = CD(C_SOL + 3, t),
                      v = CD(C_SOL + 4, t), w = CD(C_SOL + 5, t);
+        const SinCos scw_ = sincos_of(yaw);
+        const double syw = scw_.s, cyw = scw_.c;
         if (t < Nm) {
-          const double r1 = x + v * cos(yaw) * P.dt - SH(carry2, 0, t + 1);
-          const double r2 = y + v * sin(yaw) * P.dt - SH(carry2, 1, t + 1);
-          const double r3 = yaw + v * tan(stv) / P.WB * P.dt - SH(carry2, 2, t + 1);
+          const double r1 = x + v * cyw * P.dt - SH(carry2, 0, t + 1);
+          const double r2 = y + v * syw * P.dt - SH(carry2, 1, t + 1);
+          const double r3 = yaw + v * tan_of(stv) / P.WB * P.dt - SH(carry2, 2, t + 1);
           const double r4 = stv + w * P.dt - SH(carry2, 3, t + 1);
           p[0] = r1 * r1;
           p[1] = r2 * r2;
           p[2] = r3 * r3;
           p[3] = r4 * r4;
         }
-        const double Y[4] = {x + P.f2x * cos(yaw), y + P.f2x * sin(yaw), x + P.r2x * cos(yaw), y + P.r2x * sin(yaw)};
+        const double Y[4] = {x + P.f2x * cyw, y + P.f2x * syw, x + P.r2x * cyw, y + P.r2x * syw};
         double ecor = 0.0;
         CSDO_FOR(k, 4, {
           const double lbk = CD(C_CLB + k, t), ubk = CD(C_CUB + k, t);
@@ -2521,7 +2527,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_SLANES(t) {  // updateCorridor :818-872 (double-precision disc centres): rear disc on the solver lane
       if (!P.fixed_corridor) {
         const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
-        const double xr = px + P.r2x * cos(pyaw), yr = py + P.r2x * sin(pyaw);
+        const SinCos scp_ = sincos_of(pyaw);
+        const double spy = scp_.s, cpy = scp_.c;
+        const double xr = px + P.r2x * cpy, yr = py + P.r2x * spy;
         BoxD br;
         make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
         CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
@@ -2531,7 +2539,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     CSDO_LANES(t) {  // solution0 = solution; front disc on the row lane
       if (!P.fixed_corridor) {
         const double px = CD(C_SOL + 0, t), py = CD(C_SOL + 1, t), pyaw = CD(C_SOL + 2, t);
-        const double xf = px + P.f2x * cos(pyaw), yf = py + P.f2x * sin(pyaw);
+        const SinCos scp_ = sincos_of(pyaw);
+        const double spy = scp_.s, cpy = scp_.c;
+        const double xf = px + P.f2x * cpy, yf = py + P.f2x * spy;
         BoxD bf;
         make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
         CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;

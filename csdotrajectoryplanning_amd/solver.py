@@ -286,6 +286,15 @@ class DsqpHandle:
                                         abi.as_double_p(boxes), abi.as_int32_p(status)), "csdo_generate_boxes")
         return boxes, status
 
+    def math_eval(self, fn, a, b=None):
+        """Diagnostic: the device program's sin (fn 0), cos (1), tan (2) of a, atan2 (3) of (a, b), evaluated on the device."""
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        b = a if b is None else np.ascontiguousarray(b, dtype=np.float64).ravel()
+        out = np.zeros_like(a)
+        check(lib().csdo_math_eval(self._h, int(fn), abi.as_double_p(a), abi.as_double_p(b), abi.as_double_p(out), a.size),
+              "csdo_math_eval")
+        return out
+
 
 class SolverDSQP:
     """Drop-in shape of the reference class: the constructor solves (sqp/dsqp_solver.cc:1133-1249)."""

@@ -308,6 +308,13 @@ int csdo_validate_frames(csdo_handle h, const double* solutions /* [Na][Nt][6] *
 int csdo_generate_boxes(csdo_handle h, const double* points_xy, int32_t n, const double* obstacles, int32_t n_obs,
                         double dimx, double dimy, const csdo_vehicle* veh, double* boxes, int32_t* status);
 
+/* Diagnostic: the device program's own sin (fn 0), cos (1), tan (2) of a[i] and atan2 (3) of (a[i], b[i]) - csrc/csdo_math.h, the
+ * ONE implementation every build of the program uses where the reference calls the C library's (sqp/dsqp_solver.cc:646-744,
+ * 828-831, 336-339, sqp/corridor.cc:84-122) - evaluated on the device.  The same header compiled by g++ returns the same bits
+ * (tests/test_shared_math.py); that is what makes the HIP build and its lane-serial host build agree to the bit over a whole
+ * SQP chain.  b may be null unless fn == 3. */
+int csdo_math_eval(csdo_handle h, int32_t fn, const double* a, const double* b, double* out, int32_t n);
+
 /* The shipped config.yaml evaluated the way readAgentConfig / readQpSolverConfig do. */
 void csdo_vehicle_default(csdo_vehicle* v);
 void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p);

@@ -12,6 +12,23 @@
 #include <functional>
 #include <thread>
 
+// The solve's sin / cos / tan / atan2 (the sites that have a counterpart in the device program; the bridge keeps std::).  Default:
+// the C library's, as the reference.  -DCSDO_ORACLE_SHARED_TRIG (oracle/Makefile: libcsdo_oracle_xm.so): the device program's own
+// functions (csrc/csdo_math.h, same bits in every build) - the oracle's formulation with the product's trigonometry, which
+// separates "another libm" from "another formulation" in the chain-parity report.  Never a parity target by itself.
+#if defined(CSDO_ORACLE_SHARED_TRIG)
+#include "../csdotrajectoryplanning_amd/csrc/csdo_math.h"
+#define XSIN(x) csdo::xm::sin(x)
+#define XCOS(x) csdo::xm::cos(x)
+#define XTAN(x) csdo::xm::tan(x)
+#define XATAN2(y, x) csdo::xm::atan2(y, x)
+#else
+#define XSIN(x) std::sin(x)
+#define XCOS(x) std::cos(x)
+#define XTAN(x) std::tan(x)
+#define XATAN2(y, x) std::atan2(y, x)
+#endif
+
 namespace csdo_oracle {
 
 using clk = std::chrono::steady_clock;
@@ -39,13 +56,13 @@ float normalize_angle_abs_in_pi(double x) {  // motion_planning.h:70-75 (returns
 
 DiscCentres state_discs(double x, double y, double yaw, const Vehicle& v) {  // State ctor, :115-132
   DiscCentres d;
-  d.xf = (float)(x + v.f2x * std::cos(yaw));
-  d.xr = (float)(x + v.r2x * std::cos(yaw));
-  d.yf = (float)(y + v.f2x * std::sin(yaw));
-  d.yr = (float)(y + v.r2x * std::sin(yaw));
+  d.xf = (float)(x + v.f2x * XCOS(yaw));
+  d.xr = (float)(x + v.r2x * XCOS(yaw));
+  d.yf = (float)(y + v.f2x * XSIN(yaw));
+  d.yr = (float)(y + v.r2x * XSIN(yaw));
   const float d_center2real = (v.LF + v.LB) / 2 - v.LB;
-  d.xc = (float)(x + d_center2real * std::cos(yaw));
-  d.yc = (float)(y + d_center2real * std::sin(yaw));
+  d.xc = (float)(x + d_center2real * XCOS(yaw));
+  d.yc = (float)(y + d_center2real * XSIN(yaw));
   return d;
 }
 
@@ -348,15 +365,15 @@ bool generate_legal_point(const Obstacle& hit, const std::vector<Obstacle>& obs,
                           double& x, double& y, const Vehicle& v, Box& res) {
   const int n_cand = 20;
   const double x0 = x, y0 = y;
-  const double theta0 = std::atan2(y0 - hit.y, x0 - hit.x);
+  const double theta0 = XATAN2(y0 - hit.y, x0 - hit.x);
   const double d_safe = 0.2;
   const double d = v.rv + hit.r + d_safe;
   for (int i = 0; i < n_cand; ++i) {
     int j = i / 2;
     if (i % 2 == 1) j = -j;
     const double theta = theta0 + j * 2 * M_PI / n_cand;
-    x = hit.x + d * std::cos(theta);
-    y = hit.y + d * std::sin(theta);
+    x = hit.x + d * XCOS(theta);
+    y = hit.y + d * XSIN(theta);
     if (x > v.rv && x < dimx - v.rv && y > v.rv && y < dimy - v.rv) {
       Box box{0, 0, 0, 0};
       generate_local_box(x, y, obs, dimx, dimy, v, box);
@@ -441,8 +458,8 @@ void assemble_qp(int Nt, const std::vector<double>& s, const std::vector<double>
   int si = 0;
   // ---- calcKineConstraint, :646-744 ----
   for (int k = 0; k < Nm; ++k) {
-    const double syaw = std::sin(yaw0[k]), cyaw = std::cos(yaw0[k]);
-    const double cst = std::cos(st0[k]);
+    const double syaw = XSIN(yaw0[k]), cyaw = XCOS(yaw0[k]);
+    const double cst = XCOS(st0[k]);
     const double a_yaw1 = -dt * (v0[k] * syaw);
     const double a_yaw2 = dt * (v0[k] * cyaw);
     const double a_steer = (dt / WB * v0[k]) / std::pow(cst, 2);
@@ -460,7 +477,7 @@ void assemble_qp(int Nt, const std::vector<double>& s, const std::vector<double>
     T.add(si + 2 * Nm + k, oYaw + k, 1);
     T.add(si + 2 * Nm + k, oYaw + k + 1, -1);
     T.add(si + 2 * Nm + k, oSt + k, a_steer);
-    T.add(si + 2 * Nm + k, oV + k, dt / WB * std::tan(st0[k]));
+    T.add(si + 2 * Nm + k, oV + k, dt / WB * XTAN(st0[k]));
     // steer rows
     T.add(si + 3 * Nm + k, oSt + k, 1);
     T.add(si + 3 * Nm + k, oSt + k + 1, -1);
@@ -489,7 +506,7 @@ void assemble_qp(int Nt, const std::vector<double>& s, const std::vector<double>
   std::vector<double> E(4 * Nt);
   std::vector<double> Dyaw(4 * Nt);  // yaw coefficient of rows xf,yf,xr,yr
   for (int t = 0; t < Nt; ++t) {
-    const double sy = std::sin(yaw0[t]), cy = std::cos(yaw0[t]);
+    const double sy = XSIN(yaw0[t]), cy = XCOS(yaw0[t]);
     Dyaw[t] = -f2x * sy;
     Dyaw[Nt + t] = f2x * cy;
     Dyaw[2 * Nt + t] = -r2x * sy;
@@ -593,9 +610,9 @@ bool is_feasible(int Nt, const std::vector<double>& s, const AgentCtx& ctx, cons
   const double* w = &s[4 * Nt + Nt - 1];
   double e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   for (int k = 0; k < Nt - 1; ++k) {
-    const double r1 = x[k] + v[k] * std::cos(yaw[k]) * dt - x[k + 1];
-    const double r2 = y[k] + v[k] * std::sin(yaw[k]) * dt - y[k + 1];
-    const double r3 = yaw[k] + v[k] * std::tan(st[k]) / WB * dt - yaw[k + 1];
+    const double r1 = x[k] + v[k] * XCOS(yaw[k]) * dt - x[k + 1];
+    const double r2 = y[k] + v[k] * XSIN(yaw[k]) * dt - y[k + 1];
+    const double r3 = yaw[k] + v[k] * XTAN(st[k]) / WB * dt - yaw[k + 1];
     const double r4 = st[k] + w[k] * dt - st[k + 1];
     e1 += r1 * r1;
     e2 += r2 * r2;
@@ -606,10 +623,10 @@ bool is_feasible(int Nt, const std::vector<double>& s, const AgentCtx& ctx, cons
   if (err_kin > th_kin) return false;
   std::vector<double> Y(4 * Nt);
   for (int t = 0; t < Nt; ++t) {
-    Y[t] = x[t] + veh.f2x * std::cos(yaw[t]);
-    Y[Nt + t] = y[t] + veh.f2x * std::sin(yaw[t]);
-    Y[2 * Nt + t] = x[t] + veh.r2x * std::cos(yaw[t]);
-    Y[3 * Nt + t] = y[t] + veh.r2x * std::sin(yaw[t]);
+    Y[t] = x[t] + veh.f2x * XCOS(yaw[t]);
+    Y[Nt + t] = y[t] + veh.f2x * XSIN(yaw[t]);
+    Y[2 * Nt + t] = x[t] + veh.r2x * XCOS(yaw[t]);
+    Y[3 * Nt + t] = y[t] + veh.r2x * XSIN(yaw[t]);
   }
   double err_cor_max = 0;
   for (int i = 0; i < 4 * Nt; ++i)
@@ -637,8 +654,8 @@ void update_corridor(int Nt, const std::vector<double>& s, const DsqpProblem& pr
   const Vehicle& veh = prob.veh;
   for (int t = 0; t < Nt; ++t) {
     const double x = s[t], y = s[Nt + t], yaw = s[2 * Nt + t];
-    const double xf = x + veh.f2x * std::cos(yaw), xr = x + veh.r2x * std::cos(yaw);
-    const double yf = y + veh.f2x * std::sin(yaw), yr = y + veh.r2x * std::sin(yaw);
+    const double xf = x + veh.f2x * XCOS(yaw), xr = x + veh.r2x * XCOS(yaw);
+    const double yf = y + veh.f2x * XSIN(yaw), yr = y + veh.r2x * XSIN(yaw);
     Box bf{0, 0, 0, 0}, br{0, 0, 0, 0};
     generate_box(prob.dimx, prob.dimy, xf, yf, prob.obstacles, veh, bf);
     generate_box(prob.dimx, prob.dimy, xr, yr, prob.obstacles, veh, br);

@@ -158,3 +158,21 @@ extern "C" int csdo_emu_generate_boxes(const double* pts, int32_t n, const doubl
   }
   return CSDO_OK;
 }
+
+// the shared trigonometry (csrc/csdo_math.h) as this host build compiles it; fn 0 sin, 1 cos, 2 tan, 3 atan2(a, b); 10..13: the C library's
+extern "C" int csdo_emu_math_eval(int32_t fn, const double* a, const double* b, double* out, int32_t n) {
+  for (int i = 0; i < n; ++i) {
+    switch (fn) {
+      case 0: out[i] = sincos_of(a[i]).s; break;
+      case 1: out[i] = sincos_of(a[i]).c; break;
+      case 2: out[i] = tan_of(a[i]); break;
+      case 3: out[i] = atan2_of(a[i], b[i]); break;
+      case 10: out[i] = std::sin(a[i]); break;
+      case 11: out[i] = std::cos(a[i]); break;
+      case 12: out[i] = std::tan(a[i]); break;
+      case 13: out[i] = std::atan2(a[i], b[i]); break;
+      default: return CSDO_EINVAL;
+    }
+  }
+  return CSDO_OK;
+}

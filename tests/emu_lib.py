@@ -27,7 +27,17 @@ def lib():
                                                  C.c_int]
         _LIB.csdo_emu_generate_boxes.argtypes = [abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                                  C.c_double, C.POINTER(abi.Vehicle), abi.c_double_p, abi.c_int32_p]
+        _LIB.csdo_emu_math_eval.argtypes = [C.c_int32, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_int32]
     return _LIB
+
+
+def math_eval(fn, a, b=None):
+    """csrc/csdo_math.h as the host build compiles it (fn 0 sin, 1 cos, 2 tan, 3 atan2(a, b); 10..13 the C library's)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros_like(a)
+    assert lib().csdo_emu_math_eval(fn, abi.as_double_p(a), abi.as_double_p(b), abi.as_double_p(out), a.size) == 0
+    return out
 
 
 def solve_batch_rc(worlds, mode=0, n_threads=1):

@@ -35,27 +35,37 @@ def lib():
     return _LIB
 
 
-_FMA = None
+_VARIANTS = {}
 
 
-def solve_batch_fma(worlds, n_threads=1):
-    """The same oracle source built with fused multiply-adds (oracle/Makefile: libcsdo_oracle_fma.so): how sensitive the
-    reference algorithm itself is to rounding.  Never a parity target."""
-    global _FMA
-    if _FMA is None:
-        path = os.path.join(_ROOT, "oracle", "libcsdo_oracle_fma.so")
+def solve_batch_variant(worlds, variant, n_threads=1):
+    """The same oracle source in another build (oracle/Makefile).  "fma": fused multiply-adds everywhere - how sensitive the
+    reference algorithm itself is to rounding; "xm": the device program's own sin / cos / tan / atan2 (csrc/csdo_math.h) -
+    the oracle's formulation with the product's trigonometry.  Never parity targets."""
+    if variant not in _VARIANTS:
+        name = "libcsdo_oracle_%s.so" % variant
+        path = os.path.join(_ROOT, "oracle", name)
         if not os.path.exists(path):
-            subprocess.run(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "libcsdo_oracle_fma.so"], check=True)
-        _FMA = C.CDLL(path)
-        _FMA.csdo_oracle_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
+            subprocess.run(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), name], check=True)
+        lib_ = C.CDLL(path)
+        lib_.csdo_oracle_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
+        _VARIANTS[variant] = lib_
     sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
     probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
     res = (abi.Result * len(worlds))(*[s._c for s in sols])
-    assert _FMA.csdo_oracle_solve_batch(probs, len(worlds), res, n_threads) == 0
+    assert _VARIANTS[variant].csdo_oracle_solve_batch(probs, len(worlds), res, n_threads) == 0
     for s, r in zip(sols, res):
         s._c = r
         s.finish()
     return sols
+
+
+def solve_batch_fma(worlds, n_threads=1):
+    return solve_batch_variant(worlds, "fma", n_threads)
+
+
+def solve_batch_xm(worlds, n_threads=1):
+    return solve_batch_variant(worlds, "xm", n_threads)
 
 
 def solve(world: World, n_threads=1) -> Solution:

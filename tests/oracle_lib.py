@@ -42,14 +42,7 @@ def solve_batch_variant(worlds, variant, n_threads=1):
     """The same oracle source in another build (oracle/Makefile).  "fma": fused multiply-adds everywhere - how sensitive the
     reference algorithm itself is to rounding; "xm": the device program's own sin / cos / tan / atan2 (csrc/csdo_math.h) -
     the oracle's formulation with the product's trigonometry.  Never parity targets."""
-    if variant not in _VARIANTS:
-        name = "libcsdo_oracle_%s.so" % variant
-        path = os.path.join(_ROOT, "oracle", name)
-        if not os.path.exists(path):
-            subprocess.run(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), name], check=True)
-        lib_ = C.CDLL(path)
-        lib_.csdo_oracle_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
-        _VARIANTS[variant] = lib_
+    _variant_lib(variant)
     sols = [Solution.allocate(w.Na, w.Nt) for w in worlds]
     probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
     res = (abi.Result * len(worlds))(*[s._c for s in sols])
@@ -115,13 +108,28 @@ def preprocess(states, actions, path_off, goals, veh, parm, inst):
     return out
 
 
-def generate_boxes(points, obstacles, dimx, dimy, veh):
+def _variant_lib(variant):
+    if variant not in _VARIANTS:
+        name = "libcsdo_oracle_%s.so" % variant
+        path = os.path.join(_ROOT, "oracle", name)
+        if not os.path.exists(path):
+            subprocess.run(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), name], check=True)
+        lib_ = C.CDLL(path)
+        lib_.csdo_oracle_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
+        lib_.csdo_oracle_generate_boxes.argtypes = lib().csdo_oracle_generate_boxes.argtypes
+        _VARIANTS[variant] = lib_
+    return _VARIANTS[variant]
+
+
+def generate_boxes(points, obstacles, dimx, dimy, veh, variant=None):
+    """variant "xm": the oracle built with the device program's own sin / cos / atan2 (the repair path of a point inside an
+    inflated obstacle, generateLegalPoint, is the only part of a box that calls them)."""
     points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
     obstacles = np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 3)
     n = points.shape[0]
     boxes = np.zeros((n, 4))
     status = np.zeros(n, np.int32)
-    lib().csdo_oracle_generate_boxes(abi.as_double_p(points), n, abi.as_double_p(obstacles), obstacles.shape[0],
+    (lib() if variant is None else _variant_lib(variant)).csdo_oracle_generate_boxes(abi.as_double_p(points), n, abi.as_double_p(obstacles), obstacles.shape[0],
                                      dimx, dimy, C.byref(veh), abi.as_double_p(boxes), abi.as_int32_p(status))
     return boxes, status
 

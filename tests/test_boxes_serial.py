@@ -21,4 +21,14 @@ def test_boxes_bit_identical_on_random_maps(veh_parm, oracle, emu):
         bo, so = oracle.generate_boxes(pts, obs, dim, dim, veh)
         be, se = emu.generate_boxes(pts, obs, dim, dim, veh)
         np.testing.assert_array_equal(so, se)
-        np.testing.assert_array_equal(bo, be)
+        # growth is compare / add arithmetic: bit for bit.  The repair of a point inside an inflated obstacle (generateLegalPoint)
+        # calls atan2 / cos / sin: the program has its own (csrc/csdo_math.h, the same bits in every build), which agree with
+        # the C library's in > 99 % of the arguments and differ by an ulp in the rest - so: bit for bit against the oracle built
+        # with the program's functions, and against the default oracle everywhere but on those points, where an ulp is allowed
+        bx, sx = oracle.generate_boxes(pts, obs, dim, dim, veh, variant="xm")
+        np.testing.assert_array_equal(sx, se)
+        np.testing.assert_array_equal(bx, be)
+        legal = (so >> 1) != 2
+        np.testing.assert_array_equal(bo[legal], be[legal])
+        np.testing.assert_allclose(bo[~legal], be[~legal], atol=1e-12, rtol=0)
+        assert np.mean(np.all(bo[~legal] == be[~legal], axis=1)) >= 0.97 if (~legal).any() else True

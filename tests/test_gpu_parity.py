@@ -230,6 +230,8 @@ def test_gpu_corridor_boxes_bit_exact(gpu_handle, oracle, veh_parm):
     legal = (so >> 1) != 2
     assert np.array_equal(bo[legal], bg[legal])                          # pure compare/add arithmetic: bit exact
     np.testing.assert_allclose(bo[~legal], bg[~legal], atol=1e-9, rtol=0)  # repair path calls atan2/cos/sin
+    bx, sx = oracle.generate_boxes(pts, world.obstacles, world.dimx, world.dimy, veh, variant="xm")   # ... the program's own: bit exact everywhere
+    assert np.array_equal(sx, sg) and np.array_equal(bx, bg)
     # empty obstacle list and empty point list
     b, s = gpu_handle.generate_boxes([[50.0, 50.0]], np.zeros((0, 3)), 100.0, 100.0, veh)
     np.testing.assert_allclose(b[0], [39.9, 39.9, 60.1, 60.1], atol=1e-9)
@@ -320,6 +322,8 @@ def test_gpu_corridor_boxes_bit_exact_in_dense_obstacle_fields(gpu_handle, oracl
     legal = (so >> 1) != 2
     assert np.array_equal(bo[legal], bg[legal])
     np.testing.assert_allclose(bo[~legal], bg[~legal], atol=1e-9, rtol=0)
+    bx, sx = oracle.generate_boxes(pts, obstacles, side, side, veh, variant="xm")
+    assert np.array_equal(sx, sg) and np.array_equal(bx, bg)
 
 
 def test_gpu_mixed_batch_launch_groups(gpu_handle, veh_parm):

@@ -113,6 +113,8 @@ def test_corridor_boxes_bit_exact(oracle, emu, veh_parm):
     assert np.array_equal(bo[legal], be[legal])
     np.testing.assert_allclose(bo[~legal], be[~legal], atol=1e-9, rtol=0)
     assert (~legal).sum() > 0 and ((so >> 1) == 1).sum() > 0
+    bx, sx = oracle.generate_boxes(pts, world.obstacles, world.dimx, world.dimy, veh, variant="xm")   # the program's own atan2 / cos / sin
+    assert np.array_equal(sx, se) and np.array_equal(bx, be)
 
 
 @pytest.mark.parametrize("n_obs", [40, 300])

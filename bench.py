@@ -10,7 +10,11 @@ its ADMM QPs) over one batch of worlds whose inputs are already resident in HBM.
            synth1024  (configs[4]) 21 worlds (ex0..ex20 of the map100 set) truncated to 1024 agents
            room50     benchmark/room/agents50 ex0..ex11: 238 obstacles per world (the obstacle-dense regime)
            agents100  benchmark/map100by100/agents100/obstacle ex0..ex11: 100 vehicles per world (the plane-dense regime)
-N > 1 ranks (torch.distributed.run, one process per GPU, RCCL):
+--gpus N > 1 without WORLD_SIZE in the environment: bench.py starts the N ranks ITSELF - a child `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <the same arguments>`, started before this process has touched the
+GPU, rank 0's JSON line comes through on the shared stdout, the exit code is the children's.  Launched under torch.distributed.run
+(WORLD_SIZE set, as the driver does for N > 1) it is one of the ranks and insists on WORLD_SIZE == --gpus.
+N > 1 ranks (one process per GPU, RCCL):
 Either way the agents of the job are SHARDED by sharding.shard_batch_plan: rank r owns one contiguous block of the job's
 concatenated agents (the reference's loop over agents is what shards, sqp/dsqp_solver.cc:1198-1220), builds only the worlds
 its block overlaps, solves its block, and the step ends with the path's only collective, the all-gather of the final
@@ -23,6 +27,9 @@ trajectories on the device pointer.
 Blocks are balanced by the launcher's own per-agent work estimate (csdo_dsqp_estimate_work), not by agent count.
 --force-dist          N = 1 with a one-rank "nccl" group: RCCL initialisation, the all-gather on the solver's device buffer
                       and the stream ordering run on the one GPU there is
+--dry                 CPU check of the N-rank plumbing (tests/test_bench_launch.py): backend gloo, no GPU, the lane-serial host build
+                      of the device program (tests/emu) as the solver: plan, shard, solve, stage / collect, the JSON line with
+                      n_gpus = the group's size and `value` null - a dry line is not a measurement
 Rank 0 prints ONE JSON line.
 
 metric  = agent-QP-iterations/sec: ADMM iterations executed by all agents of all ranks / wall time of the K steps (max
@@ -116,6 +123,55 @@ def _newest_pmc(workload, step_ms):
     return None, None, None, None
 
 
+def _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong):
+    """--dry: the N-rank step on the CPU - gloo group, this rank's block solved by the lane-serial host build of the device program
+    (tests/emu, test infrastructure), FlatGather.stage / collect as in the GPU step - and rank 0's line.  Nothing here is timed as a
+    result: `value` is null."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from csdotrajectoryplanning_amd import sharding
+    from tests import emu_lib
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
+    dev = torch.device("cpu")
+    n_dbl = int(sum(w.Na * w.Nt * 6 for w in worlds))
+    fg = sharding.FlatGather(n_dbl, dist, dev)
+    iters_step, local = 0, None
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        sols = emu_lib.solve_batch(worlds, 0, max(1, (os.cpu_count() or 2) // world_size))
+        local = torch.from_numpy(np.concatenate([s.solutions.reshape(-1) for s in sols]) if sols else np.zeros(0))
+        fg.stage(local)
+        fg.collect()
+        iters_step = int(sum(int(s.admm_iters.sum()) for s in sols))
+    elapsed = time.perf_counter() - t0
+    mine = fg.parts()[rank]
+    ok = bool(torch.equal(mine, local)) and fg.lengths[rank] == n_dbl
+    t = torch.tensor([float(iters_step), float(sum(w.Na for w in worlds)), float(ok)], dtype=torch.float64)
+    allr = [torch.zeros_like(t) for _ in range(world_size)]
+    dist.all_gather(allr, t)
+    gathered_sha = None
+    if rank == 0:
+        import hashlib
+        gathered_sha = hashlib.sha256(np.concatenate([p.numpy() for p in fg.parts()]).tobytes()).hexdigest()
+    n_ranks = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "agent_qp_iterations_per_sec", "value": None, "unit": "agent-QP-iterations/s", "dry": True,
+            "n_gpus": n_ranks, "rccl_ranks": None, "gloo_ranks": n_ranks, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "dry run on the CPU (lane-serial host build of the device program): plumbing only, no measurement",
+            "config": {"workload_key": args.workload, "worlds_total": len(jobs), "agents_total": int(sum(sizes)),
+                       "per_rank": [{"rank": r, "agents": int(v[1]), "admm_iterations_per_step": int(v[0]),
+                                     "gathered_block_equals_local": bool(v[2])} for r, v in enumerate(allr)],
+                       "shard_balance": shard_balance, "gathered_doubles": int(sum(fg.lengths)),
+                       "gathered_sha256": gathered_sha, "wall_s": elapsed}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,11 +194,31 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive DO-phase measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: run the sharded path with a one-rank nccl group (RCCL init, all-gather on the device buffer)")
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU check of the multi-rank plumbing: gloo, no GPU, the lane-serial host build as the solver; not a measurement")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # One process per GPU, started HERE: fresh children (no exec of this process, which must not have touched the GPU - it has
+        # not: nothing above imports torch or the library), rank 0's line on the inherited stdout, the children's exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or without "
+                         "torch.distributed.run: bench.py starts its ranks itself)" % (args.gpus, world_size))
     strong = args.scaling == "strong"
     copies = 1 if (strong or world_size == 1) else world_size
     sharded = world_size > 1 or args.force_dist
@@ -204,6 +280,8 @@ def main():
     t_pre = time.perf_counter() - t_pre0
 
     import numpy as np
+    if args.dry:
+        return _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong)
     from csdotrajectoryplanning_amd.solver import DsqpHandle, interpolate_and_planes
     n_front = sum(1 for i in infos if str(i["generator"]).startswith("front_end"))
     guesses = ("initial guesses: %d worlds from this repository's front end (PBS over hybrid A*, paths stored by "
@@ -549,6 +627,7 @@ def main():
             "value": value,
             "unit": "agent-QP-iterations/s",
             "n_gpus": world_size,
+            "rccl_ranks": (dist.get_world_size() if dist is not None else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / steps * 1e3,

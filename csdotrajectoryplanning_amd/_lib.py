@@ -35,6 +35,12 @@ def lib():
         H = C.c_void_p
         L.csdo_backend_name.restype = C.c_char_p
         L.csdo_dsqp_create.argtypes = [C.POINTER(H), C.c_int]
+        L.csdo_dsqp_create_multi.argtypes = [C.POINTER(H), abi.c_int32_p, C.c_int32]
+        L.csdo_dsqp_multi_count.argtypes = [H]
+        L.csdo_dsqp_multi_count.restype = C.c_int32
+        L.csdo_dsqp_multi_child.argtypes = [H, C.c_int32]
+        L.csdo_dsqp_multi_child.restype = H
+        L.csdo_dsqp_shard_bounds.argtypes = [abi.c_double_p, C.c_int32, C.c_int32, abi.c_int32_p]
         L.csdo_dsqp_destroy.argtypes = [H]
         L.csdo_dsqp_destroy.restype = None
         L.csdo_dsqp_solve.argtypes = [H, C.POINTER(abi.Problem), C.POINTER(abi.Result)]

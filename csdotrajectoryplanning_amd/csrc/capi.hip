@@ -69,7 +69,22 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 }  // namespace
 
+// Several GPUs behind one handle (csdo_dsqp_create_multi): one child handle per device, the batch's agents cut into contiguous
+// blocks of equal estimated work (the reference's loop over agents, sqp/dsqp_solver.cc:1198-1220, is what shards), every child
+// driven by a host thread of its own, results scattered straight into the caller's arrays.
+struct MultiPart { int world, lo, hi; };   // agents [lo, hi) of the caller's world `world`
+struct MultiState {
+  std::vector<csdo_handle> kids;
+  std::vector<std::vector<MultiPart>> parts;               // per child: its block, world by world
+  std::vector<std::vector<csdo_problem>> probs;            // ... as (sub-)problems: views into the caller's arrays
+  std::vector<std::vector<std::vector<int32_t>>> offs;     // ... with the plane offsets of a cut world re-based
+  std::vector<std::vector<csdo_result>> res;               // per child: views into the caller's results (download)
+  std::vector<int> world_na;                               // agents per world of the uploaded batch
+  int n_worlds = 0;
+};
+
 struct csdo_handle_s {
+  MultiState* multi = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -99,6 +114,8 @@ struct csdo_handle_s {
   int64_t limit_bytes = 0;
   double t_pack = 0, t_stage = 0, t_h2d = 0, t_d2h = 0, t_unpack = 0;   // host seconds of the last upload / download
   DeviceBatch dev{};
+  hipStream_t copy = nullptr;  // the stream of upload's H2D and download's D2H: the handle's own stream, or - a shared handle - a private
+                               // one, so that a copy never queues up behind another batch's persistent kernels on a lent stream
   bool borrowed = false;       // csdo_dsqp_create_shared: the streams belong to another handle (never destroyed here)
   hipStream_t four[4] = {nullptr, nullptr, nullptr, nullptr};   // ... the owner's four streams
   bool run_pending = false;    // csdo_dsqp_run_async has been called and csdo_dsqp_wait has not
@@ -221,6 +238,248 @@ static int guarded(F&& f) {
   }
 }
 
+static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds);
+static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Several GPUs behind one handle (csdo_dsqp_create_multi)
+// ---------------------------------------------------------------------------------------------------------------------
+// Contiguous blocks [cuts[r], cuts[r + 1]) of near-equal total weight: block r ends where the running sum first reaches
+// (r + 1) / n_blocks of the total - the closer of the two candidate cuts -, every block keeps at least one item while there are
+// enough (the rule of sharding.py: shard_bounds_weighted, which the N-process path uses; tests/test_multi_host.py holds them equal).
+static std::vector<int> weighted_cuts(const double* w, int n, int n_blocks) {
+  std::vector<int> cuts{0};
+  std::vector<double> cum((size_t)std::max(n, 0));
+  double total = 0.0;
+  for (int i = 0; i < n; ++i) {
+    total += w[i] > 0.0 ? w[i] : 0.0;
+    cum[(size_t)i] = total;
+  }
+  for (int r = 1; r < n_blocks; ++r) {
+    int i;
+    if (!(total > 0.0)) {   // no information: equal counts
+      const int base = n / n_blocks, rem = n % n_blocks;
+      i = r * base + std::min(r, rem);
+    } else {
+      const double target = total * r / n_blocks;
+      i = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin()) + 1;
+      if (i - 1 > cuts.back() && i >= 2 && std::fabs(cum[(size_t)i - 2] - target) <= std::fabs(cum[(size_t)std::min(i, n) - 1] - target)) i -= 1;
+      const int left = n - cuts.back(), behind = n_blocks - r;
+      i = std::max(i, cuts.back() + (left > behind ? 1 : 0));
+      i = std::min(i, left > behind ? n - std::min(behind, left) : n);
+    }
+    cuts.push_back(std::min(std::max(i, cuts.back()), n));
+  }
+  cuts.push_back(std::max(n, 0));
+  return cuts;
+}
+
+// f(k) for every child, each on a host thread of its own (child 0 on the caller's); a thread that cannot be had runs inline, and
+// no exception leaves a joinable thread behind.  Returns the first error.
+template <class F>
+static int for_each_kid(MultiState& M, F&& f) {
+  const int n = (int)M.kids.size();
+  std::vector<int> rc((size_t)n, CSDO_OK);
+  struct Joiner {
+    std::vector<std::thread> t;
+    ~Joiner() {
+      for (auto& x : t)
+        if (x.joinable()) x.join();
+    }
+  } pool;
+  auto run = [&](int k) {
+    try {
+      rc[(size_t)k] = f(k);
+    } catch (const std::bad_alloc&) {
+      rc[(size_t)k] = CSDO_ENOMEM;
+    } catch (...) {
+      rc[(size_t)k] = CSDO_EDEVICE;
+    }
+  };
+  try {
+    pool.t.reserve((size_t)n);
+  } catch (...) {
+  }
+  for (int k = 1; k < n; ++k) {
+    try {
+      pool.t.emplace_back(run, k);
+    } catch (...) {
+      run(k);
+    }
+  }
+  run(0);
+  for (auto& x : pool.t) x.join();
+  pool.t.clear();
+  for (int k = 0; k < n; ++k)
+    if (rc[(size_t)k] != CSDO_OK) return rc[(size_t)k];
+  return CSDO_OK;
+}
+
+static int multi_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
+  MultiState& M = *h->multi;
+  for (csdo_handle kid : M.kids)
+    if (kid->run_pending) return CSDO_EINVAL;
+  h->uploaded = false;
+  h->limit_world = h->limit_agent = -1;
+  h->limit_bytes = 0;
+  const double t0 = now_s();
+  HostBatch all;   // validates the batch and yields the per-agent work estimate (csdo_dsqp_estimate_work's)
+  int rc = pack_worlds(worlds, n_worlds, all);
+  if (rc != CSDO_OK) return rc;
+  const int nk = (int)M.kids.size(), Na = (int)all.agents.size();
+  std::vector<double> est((size_t)Na);
+  for (int a = 0; a < Na; ++a) est[(size_t)a] = (double)all.est_work[(size_t)a];
+  const std::vector<int> cuts = weighted_cuts(est.data(), Na, nk);
+  M.n_worlds = n_worlds;
+  M.world_na.assign((size_t)n_worlds, 0);
+  for (int w = 0; w < n_worlds; ++w) M.world_na[(size_t)w] = worlds[w].Na;
+  M.parts.assign((size_t)nk, {});
+  M.probs.assign((size_t)nk, {});
+  M.offs.assign((size_t)nk, {});
+  for (int k = 0; k < nk; ++k) {
+    const int lo = cuts[(size_t)k], hi = cuts[(size_t)k + 1];
+    for (int w = 0; w < n_worlds && lo < hi; ++w) {
+      const int first = all.world_first_agent[(size_t)w], last = all.world_first_agent[(size_t)w + 1];
+      const int a = std::max(lo, first), b = std::min(hi, last);
+      if (b <= a) continue;
+      M.parts[(size_t)k].push_back(MultiPart{w, a - first, b - first});
+    }
+    M.offs[(size_t)k].resize(M.parts[(size_t)k].size());
+    for (size_t i = 0; i < M.parts[(size_t)k].size(); ++i) {
+      const MultiPart& pt = M.parts[(size_t)k][i];
+      csdo_problem P = worlds[pt.world];
+      if (pt.lo > 0 || pt.hi < P.Na) {   // a cut world: agents [lo, hi) of it, plane offsets re-based
+        std::vector<int32_t>& off = M.offs[(size_t)k][i];
+        off.resize((size_t)(pt.hi - pt.lo) + 1);
+        const int32_t base = P.plane_off[pt.lo];
+        for (int j = 0; j <= pt.hi - pt.lo; ++j) off[(size_t)j] = P.plane_off[pt.lo + j] - base;
+        P.x0_bar += (size_t)pt.lo * (size_t)P.Nt * 6;
+        P.planes += base;
+        P.plane_off = off.data();
+        P.Na = pt.hi - pt.lo;
+      }
+      M.probs[(size_t)k].push_back(P);
+    }
+  }
+  const double t_plan = now_s() - t0;
+  rc = for_each_kid(M, [&](int k) {
+    csdo_handle kid = M.kids[(size_t)k];
+    kid->uploaded = false;
+    if (M.probs[(size_t)k].empty()) return (int)CSDO_OK;   // more devices than agents
+    return upload_impl(kid, M.probs[(size_t)k].data(), (int32_t)M.probs[(size_t)k].size());
+  });
+  if (rc == CSDO_ELIMIT)
+    for (int k = 0; k < nk && h->limit_world < 0; ++k) {
+      const csdo_handle kid = M.kids[(size_t)k];
+      if (kid->limit_world < 0 || kid->limit_world >= (int)M.parts[(size_t)k].size()) continue;
+      const MultiPart& pt = M.parts[(size_t)k][(size_t)kid->limit_world];
+      h->limit_world = pt.world;
+      h->limit_agent = pt.lo + kid->limit_agent;
+      h->limit_bytes = kid->limit_bytes;
+    }
+  if (rc != CSDO_OK) return rc;
+  h->t_pack = h->t_stage = h->t_h2d = 0.0;
+  for (csdo_handle kid : M.kids) {   // the children work side by side: the slowest one's times, plus the plan
+    h->t_pack = std::max(h->t_pack, kid->t_pack);
+    h->t_stage = std::max(h->t_stage, kid->t_stage);
+    h->t_h2d = std::max(h->t_h2d, kid->t_h2d);
+  }
+  h->t_pack += t_plan;
+  h->n_worlds = n_worlds;
+  h->uploaded = true;
+  return CSDO_OK;
+}
+
+static int multi_run_async(csdo_handle h, void* hip_stream) {
+  MultiState& M = *h->multi;
+  if (!h->uploaded || h->run_pending) return CSDO_EINVAL;
+  int rc = CSDO_OK;
+  size_t started = 0;
+  for (; started < M.kids.size() && rc == CSDO_OK; ++started) {
+    csdo_handle kid = M.kids[started];
+    if (!kid->uploaded) continue;
+    rc = csdo_dsqp_run_async(kid, nullptr);   // every device starts at once, on its own streams
+    // the caller's stream, if there is one, joins: what it enqueues next is ordered behind every device's solve
+    if (rc == CSDO_OK && hip_stream && hipStreamWaitEvent((hipStream_t)hip_stream, kid->ev1, 0) != hipSuccess) rc = CSDO_EDEVICE;
+  }
+  if (rc != CSDO_OK) {   // nothing keeps running behind the caller's back
+    for (size_t k = 0; k < started; ++k)
+      if (M.kids[k]->run_pending) (void)csdo_dsqp_wait(M.kids[k]);
+    return rc;
+  }
+  h->run_pending = true;
+  return CSDO_OK;
+}
+
+static int multi_wait(csdo_handle h) {
+  MultiState& M = *h->multi;
+  if (!h->run_pending) return CSDO_EINVAL;
+  h->run_pending = false;
+  int rc = CSDO_OK;
+  h->last_kernel_s = 0.0;
+  for (csdo_handle kid : M.kids) {
+    if (!kid->run_pending) continue;
+    const int r = csdo_dsqp_wait(kid);
+    if (r != CSDO_OK && rc == CSDO_OK) rc = r;
+    h->last_kernel_s = std::max(h->last_kernel_s, kid->last_kernel_s);
+  }
+  return rc;
+}
+
+static int multi_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
+  MultiState& M = *h->multi;
+  if (!h->uploaded || h->run_pending || !results || n_worlds != M.n_worlds) return CSDO_EINVAL;
+  const int nk = (int)M.kids.size();
+  M.res.assign((size_t)nk, {});
+  for (int k = 0; k < nk; ++k)
+    for (const MultiPart& pt : M.parts[(size_t)k]) {
+      const csdo_result& R = results[pt.world];
+      if (!R.solutions || !R.corridors || !R.sqp_iters || !R.admm_iters || !R.last_status) return CSDO_EINVAL;
+      const size_t Nt = (size_t)M.probs[(size_t)k][M.res[(size_t)k].size()].Nt;
+      csdo_result V{};
+      V.solutions = R.solutions + (size_t)pt.lo * Nt * 6;
+      V.corridors = R.corridors + (size_t)pt.lo * Nt * 8;
+      V.sqp_iters = R.sqp_iters + pt.lo;
+      V.admm_iters = R.admm_iters + pt.lo;
+      V.last_status = R.last_status + pt.lo;
+      V.agent_seconds = R.agent_seconds ? R.agent_seconds + pt.lo : nullptr;
+      M.res[(size_t)k].push_back(V);
+    }
+  const int rc = for_each_kid(M, [&](int k) {
+    if (M.res[(size_t)k].empty()) return (int)CSDO_OK;
+    return download_impl(M.kids[(size_t)k], M.res[(size_t)k].data(), (int32_t)M.res[(size_t)k].size());
+  });
+  if (rc != CSDO_OK) return rc;
+  // a world's scalars from all of its parts: the status rule of sqp/dsqp_solver.cc:1224-1243 over every agent of the world
+  for (int w = 0; w < n_worlds; ++w) {
+    results[w].initial_static_legal = 1;
+    results[w].t_max_individual = 0.0;
+    results[w].t_device = h->last_kernel_s;
+    bool any_bad = false;
+    int worst = 2;
+    for (int a = 0; a < M.world_na[(size_t)w]; ++a) {
+      const int st = results[w].last_status[a];
+      if (std::abs(st) > 1) {
+        any_bad = true;
+        if (std::abs(st) > worst) worst = st;
+      }
+    }
+    results[w].solver_status = any_bad ? worst : 1;
+  }
+  h->t_d2h = h->t_unpack = 0.0;
+  for (int k = 0; k < nk; ++k) {
+    for (size_t i = 0; i < M.parts[(size_t)k].size(); ++i) {
+      csdo_result& R = results[M.parts[(size_t)k][i].world];
+      const csdo_result& V = M.res[(size_t)k][i];
+      if (!V.initial_static_legal) R.initial_static_legal = 0;
+      R.t_max_individual = std::max(R.t_max_individual, V.t_max_individual);
+    }
+    h->t_d2h = std::max(h->t_d2h, M.kids[(size_t)k]->t_d2h);
+    h->t_unpack = std::max(h->t_unpack, M.kids[(size_t)k]->t_unpack);
+  }
+  return CSDO_OK;
+}
+
 extern "C" {
 
 const char* csdo_backend_name(void) { return "hip-gfx950"; }
@@ -238,8 +497,24 @@ int csdo_dsqp_create(csdo_handle* out, int device_ordinal) {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) h->n_cu = cus;
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
-    delete h;
+    csdo_dsqp_destroy(h);
     return CSDO_ENODEV;
+  }
+  h->copy = h->stream;
+  // the handle's four streams, created back to back (build_groups explains why four and why in a row); created here so that
+  // csdo_dsqp_create_shared never has to touch its parent
+  try {
+    for (int k = 0; k < 3; ++k) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        csdo_dsqp_destroy(h);
+        return CSDO_ENODEV;
+      }
+      h->side.push_back(s);
+    }
+  } catch (...) {
+    csdo_dsqp_destroy(h);
+    return CSDO_ENOMEM;
   }
   *out = h;
   return CSDO_OK;
@@ -251,14 +526,10 @@ int csdo_dsqp_create(csdo_handle* out, int device_ordinal) {
 // them).  Its groups launch all their persistent workgroups at once (no second launch): they queue up behind the workgroups
 // of the batches in front and take the CUs those release.  The parent must outlive it.
 int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane) {
-  if (!out || !parent || lane < 0) return CSDO_EINVAL;
+  if (!out || !parent || lane < 0 || parent->multi) return CSDO_EINVAL;   // (a multi-device handle has no streams to lend: use a child)
   *out = nullptr;
   HIP_OK(hipSetDevice(parent->device), CSDO_ENODEV);
-  while (parent->side.size() < 3) {
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CSDO_EDEVICE;
-    parent->side.push_back(s);
-  }
+  if (parent->side.size() < 3) return CSDO_EINVAL;
   csdo_handle h = new (std::nothrow) csdo_handle_s();
   if (!h) return CSDO_ENOMEM;
   h->device = parent->device;
@@ -268,10 +539,15 @@ int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane) 
   const hipStream_t four[4] = {parent->stream, parent->side[0], parent->side[1], parent->side[2]};
   for (int k = 0; k < 4; ++k) h->four[k] = four[k];
   h->stream = four[lane & 3];
-  for (int k = 1; k < 4; ++k) h->side.push_back(four[(lane + k) & 3]);
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
+  try {
+    for (int k = 1; k < 4; ++k) h->side.push_back(four[(lane + k) & 3]);
+  } catch (...) {
     delete h;
+    return CSDO_ENOMEM;
+  }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess) {
+    csdo_dsqp_destroy(h);
     return CSDO_ENODEV;
   }
   *out = h;
@@ -282,17 +558,74 @@ int csdo_dsqp_create_shared(csdo_handle* out, csdo_handle parent, int32_t lane) 
 // with several launch groups needs as many streams, so the caller that keeps batches in flight deals the lanes out by the
 // group counts (csdo_dsqp_launch_groups) once the batches are uploaded.  Not while a run is pending.
 int csdo_dsqp_set_lane(csdo_handle h, int32_t lane) {
-  if (!h || !h->borrowed || h->run_pending || lane < 0) return CSDO_EINVAL;
+  if (!h || h->multi || !h->borrowed || h->run_pending || lane < 0) return CSDO_EINVAL;
   h->stream = h->four[lane & 3];
   for (int k = 1; k < 4; ++k) h->side[(size_t)k - 1] = h->four[(lane + k) & 3];
   return CSDO_OK;
 }
 
+int csdo_dsqp_create_multi(csdo_handle* out, const int32_t* devices, int32_t n_devices) {
+  if (!out || !devices || n_devices < 1) return CSDO_EINVAL;
+  *out = nullptr;
+  csdo_handle h = new (std::nothrow) csdo_handle_s();
+  MultiState* M = new (std::nothrow) MultiState();
+  if (!h || !M) {
+    delete h;
+    delete M;
+    return CSDO_ENOMEM;
+  }
+  h->multi = M;
+  h->device = devices[0];
+  int rc = CSDO_OK;
+  try {
+    for (int k = 0; k < n_devices && rc == CSDO_OK; ++k) {
+      csdo_handle kid = nullptr;
+      rc = csdo_dsqp_create(&kid, devices[k]);   // the same ordinal twice: two independent handles on one GPU
+      if (rc == CSDO_OK) M->kids.push_back(kid);
+    }
+  } catch (...) {
+    rc = CSDO_ENOMEM;
+  }
+  if (rc != CSDO_OK) {
+    csdo_dsqp_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return CSDO_OK;
+}
+
+int csdo_dsqp_shard_bounds(const double* weights, int32_t n_items, int32_t n_blocks, int32_t* cuts) {
+  if (!cuts || n_items < 0 || n_blocks < 1 || (n_items > 0 && !weights)) return CSDO_EINVAL;
+  try {
+    const std::vector<int> c = weighted_cuts(weights, n_items, n_blocks);
+    for (int r = 0; r <= n_blocks; ++r) cuts[r] = c[(size_t)r];
+    return CSDO_OK;
+  } catch (...) {
+    return CSDO_ENOMEM;
+  }
+}
+
+int32_t csdo_dsqp_multi_count(csdo_handle h) { return !h ? CSDO_EINVAL : (h->multi ? (int32_t)h->multi->kids.size() : 0); }
+
+csdo_handle csdo_dsqp_multi_child(csdo_handle h, int32_t k) {
+  return (h && h->multi && k >= 0 && k < (int32_t)h->multi->kids.size()) ? h->multi->kids[(size_t)k] : nullptr;
+}
+
 void csdo_dsqp_destroy(csdo_handle h) {
   if (!h) return;
+  if (h->multi) {
+    for (csdo_handle kid : h->multi->kids) csdo_dsqp_destroy(kid);
+    delete h->multi;
+    delete h;
+    return;
+  }
   (void)hipSetDevice(h->device);
-  if (h->run_pending) (void)hipEventSynchronize(h->ev1);
-  (void)hipStreamSynchronize(h->stream);
+  if (h->run_pending && h->ev1) (void)hipEventSynchronize(h->ev1);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->borrowed && h->copy) {
+    (void)hipStreamSynchronize(h->copy);
+    (void)hipStreamDestroy(h->copy);
+  }
   for (DevBuf* b : {&h->in_arena, &h->rows_ws, &h->fac_ws,
                     &h->sol, &h->corr, &h->sqp, &h->admm, &h->stat, &h->legal, &h->ticks, &h->queues, &h->box_pts,
                     &h->box_obs, &h->box_out, &h->box_status, &h->prof, &h->k0_centres, &h->k0_counts, &h->k0_offsets,
@@ -337,9 +670,8 @@ int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double
   }
 }
 
-static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds);
-static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds);
 int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
+  if (h && h->multi) return guarded([&]() { return multi_upload(h, worlds, n_worlds); });
   return guarded([&]() { return upload_impl(h, worlds, n_worlds); });
 }
 static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
@@ -388,8 +720,16 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   }
   if ((rc = h->stage_up.ensure(total)) != CSDO_OK) return rc;
   {
-    // the big arrays (planes, x0) are copied by a few threads: a single memcpy stream does not reach the DRAM rate
-    std::vector<std::thread> pool;
+    // the big arrays (planes, x0) are copied by a few threads: a single memcpy stream does not reach the DRAM rate.  A thread
+    // that cannot be had (std::system_error under a cgroup's thread limit) copies its piece inline, and nothing unwinds through
+    // a joinable thread.
+    struct Joiner {
+      std::vector<std::thread> t;
+      ~Joiner() {
+        for (auto& x : t)
+          if (x.joinable()) x.join();
+      }
+    } pool;
     for (Item& it : items) {
       if (!it.bytes) continue;
       char* dst = (char*)h->stage_up.p + it.off;
@@ -402,15 +742,21 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
         const size_t per = ((it.bytes + parts - 1) / parts + 63) & ~(size_t)63;
         for (int k = 0; k < parts; ++k) {
           const size_t lo = (size_t)k * per, hi = std::min(it.bytes, lo + per);
-          if (lo < hi) pool.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+          if (lo >= hi) continue;
+          try {
+            pool.t.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+          } catch (...) {
+            std::memcpy(dst + lo, src + lo, hi - lo);
+          }
         }
       }
     }
-    for (auto& t : pool) t.join();
+    for (auto& t : pool.t) t.join();
+    pool.t.clear();
   }
   const double t2 = now_s();
   if ((rc = h->in_arena.ensure(total)) != CSDO_OK) return rc;
-  if (total) HIP_OK(hipMemcpyAsync(h->in_arena.p, h->stage_up.p, total, hipMemcpyHostToDevice, h->stream), CSDO_EDEVICE);
+  if (total) HIP_OK(hipMemcpyAsync(h->in_arena.p, h->stage_up.p, total, hipMemcpyHostToDevice, h->copy), CSDO_EDEVICE);
   h->t_pack = t1 - t0;
   h->t_stage = t2 - t1;
   if ((rc = h->queues.ensure(h->groups.size() * 64)) != CSDO_OK) return rc;   // one counter per group, a cache line apart
@@ -481,10 +827,10 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
 #if defined(CSDO_PROFILE_PHASES)
   if ((rc = h->prof.ensure(Na * 48 * sizeof(int64_t))) != CSDO_OK) return rc;
   B.prof = (int64_t*)h->prof.p;
-  (void)hipMemsetAsync(h->prof.p, 0, Na * 48 * sizeof(int64_t), h->stream);
+  (void)hipMemsetAsync(h->prof.p, 0, Na * 48 * sizeof(int64_t), h->copy);
 #endif
   B.prm = hb.prm;
-  HIP_OK(hipStreamSynchronize(h->stream), CSDO_EDEVICE);
+  HIP_OK(hipStreamSynchronize(h->copy), CSDO_EDEVICE);
   h->t_h2d = now_s() - t2;
   h->n_worlds = n_worlds;
   h->uploaded = true;
@@ -496,6 +842,7 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
 // must not be uploaded again or downloaded.  Work enqueued on the same stream afterwards (a copy of the device results,
 // a collective) is ordered behind the solve.
 int csdo_dsqp_run_async(csdo_handle h, void* hip_stream) {
+  if (h && h->multi) return guarded([&]() { return multi_run_async(h, hip_stream); });
   if (!h || !h->uploaded || h->run_pending) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   // after the fork an error must not leave side streams running behind the caller's back: drain the device first
@@ -538,6 +885,7 @@ int csdo_dsqp_run_async(csdo_handle h, void* hip_stream) {
 }
 
 int csdo_dsqp_wait(csdo_handle h) {
+  if (h && h->multi) return guarded([&]() { return multi_wait(h); });
   if (!h || !h->run_pending) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   h->run_pending = false;
@@ -576,6 +924,21 @@ int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]) {
 }
 
 int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents) {
+  if (h && h->multi) {   // upload order = the children's blocks one after the other; group indices continue from child to child
+    if (!h->uploaded || !group_of_agent) return CSDO_EINVAL;
+    int32_t done = 0, base = 0;
+    for (csdo_handle kid : h->multi->kids) {
+      if (!kid->uploaded) continue;
+      const int32_t n = (int32_t)kid->order.size();
+      if (done + n > n_agents) return CSDO_EINVAL;
+      const int rc = csdo_dsqp_agent_groups(kid, group_of_agent + done, n);
+      if (rc != CSDO_OK) return rc;
+      for (int32_t a = 0; a < n; ++a) group_of_agent[done + a] += base;
+      done += n;
+      base += (int32_t)kid->groups.size();
+    }
+    return done == n_agents ? CSDO_OK : CSDO_EINVAL;
+  }
   if (!h || !h->uploaded || !group_of_agent || n_agents != (int32_t)h->order.size()) return CSDO_EINVAL;
   for (int g = 0; g < (int)h->groups.size(); ++g)
     for (int i = 0; i < h->groups[g].count; ++i) group_of_agent[h->order[h->groups[g].first + i]] = g;
@@ -584,12 +947,24 @@ int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_age
 
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode) {
   if (!h || mode < 0 || mode > 3) return CSDO_EINVAL;
+  if (h->multi)
+    for (csdo_handle kid : h->multi->kids) kid->min_mode = mode;
   h->min_mode = mode;
   return CSDO_OK;
 }
 
 int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t cap) {
   if (!h || !h->uploaded || (cap > 0 && !out)) return CSDO_EINVAL;
+  if (h->multi) {   // every child's groups, child by child
+    int32_t total = 0;
+    for (csdo_handle kid : h->multi->kids) {
+      if (!kid->uploaded) continue;
+      const int32_t n = csdo_dsqp_launch_groups(kid, cap > total ? out + total : nullptr, cap > total ? cap - total : 0);
+      if (n < 0) return n;
+      total += n;
+    }
+    return total;
+  }
   const int ng = (int)h->groups.size();
   for (int g = 0; g < ng && g < cap; ++g) {
     const LaunchGroup& G = h->groups[g];
@@ -604,12 +979,13 @@ int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t c
 }
 
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles) {
-  if (!h || !h->uploaded) return nullptr;
+  if (!h || !h->uploaded || h->multi) return nullptr;   // (several devices: ask the children, csdo_dsqp_multi_child)
   if (n_doubles) *n_doubles = h->hb.steps_total * 6;
   return h->sol.p;
 }
 
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
+  if (h && h->multi) return guarded([&]() { return multi_download(h, results, n_worlds); });
   return guarded([&]() { return download_impl(h, results, n_worlds); });
 }
 static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds) {
@@ -625,7 +1001,7 @@ static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds) 
   int rc;
   if ((rc = h->stage_down.ensure(o_ticks + b_i64)) != CSDO_OK) return rc;
   char* st = (char*)h->stage_down.p;
-  hipStream_t s = h->stream;
+  hipStream_t s = h->copy;   // (the solve is over - csdo_dsqp_wait has returned -, so nothing orders this copy but itself)
   HIP_OK(hipMemcpyAsync(st, h->sol.p, b_sol, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
   HIP_OK(hipMemcpyAsync(st + o_corr, h->corr.p, b_corr, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
   HIP_OK(hipMemcpyAsync(st + o_sqp, h->sqp.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
@@ -670,6 +1046,7 @@ int csdo_dsqp_solve(csdo_handle h, const csdo_problem* in, csdo_result* out) {
 
 int csdo_generate_boxes(csdo_handle h, const double* points_xy, int32_t n, const double* obstacles, int32_t n_obs,
                         double dimx, double dimy, const csdo_vehicle* veh, double* boxes, int32_t* status) {
+  if (h && h->multi) h = h->multi->kids.empty() ? nullptr : h->multi->kids[0];   // single-device work: the first device
   if (!h || !points_xy || !veh || !boxes || !status || n < 0 || n_obs < 0 || (n_obs > 0 && !obstacles))
     return CSDO_EINVAL;
   if (n == 0) return CSDO_OK;
@@ -694,6 +1071,7 @@ int csdo_generate_boxes(csdo_handle h, const double* points_xy, int32_t n, const
 }
 
 int csdo_math_eval(csdo_handle h, int32_t fn, const double* a, const double* b, double* out, int32_t n) {
+  if (h && h->multi) h = h->multi->kids.empty() ? nullptr : h->multi->kids[0];   // single-device work: the first device
   if (!h || !a || !out || n < 0 || fn < 0 || fn > 3 || (fn == 3 && !b)) return CSDO_EINVAL;
   if (n == 0) return CSDO_OK;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
@@ -724,6 +1102,7 @@ void csdo_bridge_free(csdo_bridge_out* out) { bridge_free(out); }
 // the reference's (t, i, j) order, per-agent CSR assembly on the host.  Same outputs as csdo_preprocess, bit for bit.
 int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                            const double* goals, const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* out) {
+  if (h && h->multi) h = h->multi->kids.empty() ? nullptr : h->multi->kids[0];   // single-device work: the first device
   if (!h) return CSDO_EINVAL;
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   BridgeCentres C;
@@ -787,7 +1166,9 @@ int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* a
 int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* const* states, const int32_t* const* actions,
                                  const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
                                  const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs) {
+  if (h && h->multi) h = h->multi->kids.empty() ? nullptr : h->multi->kids[0];   // single-device work: the first device
   if (!h || n_worlds < 1 || !states || !actions || !path_off || !Na || !goals || !veh || !parm || !outs) return CSDO_EINVAL;
+  for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));   // before anything can throw: the catch below frees them
   HIP_OK(hipSetDevice(h->device), CSDO_ENODEV);
   try {
     const bool timing = std::getenv("CSDO_BRIDGE_TIMING") != nullptr;   // diagnostic: stage times to stderr
@@ -800,7 +1181,6 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
     };
     std::vector<BridgeCentres> C((size_t)n_worlds);
     std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
-    for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));
     // (parallel_for, batch_pack.h: a body that throws or a thread that cannot be created never unwinds through joinable threads)
     auto pool = [&](auto&& body) {
       if (parallel_for(n_worlds, 16, body) != CSDO_OK)
@@ -910,9 +1290,9 @@ int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const i
                           const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
                           const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs) {
   if (n_worlds < 1 || !states || !actions || !path_off || !Na || !goals || !veh || !parm || !outs) return CSDO_EINVAL;
+  for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));   // before anything can throw
   try {
     std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
-    for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));
     int rc = parallel_for(n_worlds, 16, [&](int w) {
       rcs[w] = bridge_preprocess(states[w], actions[w], path_off[w], Na[w], goals[w], veh, parm, &outs[w]);
     });
@@ -921,6 +1301,7 @@ int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const i
       for (int w = 0; w < n_worlds; ++w) bridge_free(&outs[w]);
     return rc;
   } catch (...) {
+    for (int w = 0; w < n_worlds; ++w) bridge_free(&outs[w]);
     return CSDO_ENOMEM;
   }
 }
@@ -930,6 +1311,7 @@ int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const i
 static int validate_impl(csdo_handle h, const double* solutions, int32_t Na, int32_t Nt, int32_t frames_per_move,
                          const double* obstacles, int32_t n_obs, double dimx, double dimy, const csdo_vehicle* veh, double margin,
                          csdo_validation* out) {
+  if (h && h->multi) h = h->multi->kids.empty() ? nullptr : h->multi->kids[0];   // single-device work: the first device
   if (!h || !solutions || !veh || !out || Na < 1 || Nt < 1 || n_obs < 0 || (n_obs > 0 && !obstacles) || frames_per_move < 0)
     return CSDO_EINVAL;
   // frames_per_move == 0: the Nt states as they are; S >= 1: the (Nt - 1) * S + 1 frames of the authors' animation
@@ -1043,7 +1425,7 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p) {
 #if defined(CSDO_PROFILE_PHASES)
 // diagnostic build only (libcsdo_hip_prof.so): per-agent shader-clock ticks per phase and per-agent wall ticks
 int csdo_debug_phase_ticks(csdo_handle h, int64_t* phases16, int64_t* agent_ticks) {
-  if (!h || !h->uploaded) return CSDO_EINVAL;
+  if (!h || h->multi || !h->uploaded) return CSDO_EINVAL;
   const size_t Na = h->hb.agents.size();
   if (hipMemcpy(phases16, h->prof.p, Na * 48 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
   if (hipMemcpy(agent_ticks, h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;

@@ -16,12 +16,19 @@ from .problem import Solution, World, bridge_to_world, bridge_views
 class DsqpHandle:
     """Owns one csdo_handle (device buffers + stream) on one GPU."""
 
-    def __init__(self, device=0, _parent=None, _lane=0):
+    def __init__(self, device=0, _parent=None, _lane=0, devices=None):
+        """device: one GPU ordinal.  devices: a list of ordinals - ONE handle over several GPUs (csdo_dsqp_create_multi): an upload
+        cuts the batch's agents into contiguous blocks of equal estimated work, one per device; everything else reads the same."""
         self._h = C.c_void_p()
-        if _parent is None:
+        if devices is not None:
+            devs = np.ascontiguousarray([int(d) for d in devices], dtype=np.int32)
+            check(lib().csdo_dsqp_create_multi(C.byref(self._h), abi.as_int32_p(devs), len(devs)), "csdo_dsqp_create_multi")
+            device = int(devs[0])
+        elif _parent is None:
             check(lib().csdo_dsqp_create(C.byref(self._h), int(device)), "csdo_dsqp_create")
         else:
             check(lib().csdo_dsqp_create_shared(C.byref(self._h), _parent._h, int(_lane)), "csdo_dsqp_create_shared")
+        self.devices = None if devices is None else [int(d) for d in devices]
         self.device = int(device)
         self._keep = None
         self._parent = _parent            # (keeps the owner of the streams alive)
@@ -129,44 +136,55 @@ class DsqpHandle:
         timing = {"first_launch": None, "chunks": []}
         inflight = []
         next_lane = 0
-        for c in range(len(fr)):
-            part = idx[cuts[c]:cuts[c + 1]]
-            hc = self.shared(c)
-            tb = time.perf_counter()
-            bridged = interpolate_and_planes_batch_host([items[i] for i in part], veh, parm)
-            tu = time.perf_counter()
-            hc.upload([b[0] for b in bridged])
-            tr = time.perf_counter()
-            # a batch's launch groups run side by side on streams of their own, and kernels that share a stream run one after the
-            # other: deal the four streams out by the group counts (a chunk that comes around to a stream still in use queues
-            # up behind an EARLIER, i.e. smaller, chunk's kernel)
-            ng = len(hc.launch_groups())
-            if c == 0 and (ng > 1 or mixed_by_horizon) and single_launch_if_mixed:
-                # Several kernel classes (workgroup sizes / residency modes) in the job: their CU shares are balanced per launch,
-                # and chunks of such launches in flight at once fragment the CUs (measured: map50 set 87 ms streamed against 59 ms,
-                # room set 115 against 68).  One launch of everything, on this handle, with the rest bridged at once.
-                rest = idx[cuts[1]:]
-                more = interpolate_and_planes_batch_host([items[i] for i in rest], veh, parm) if rest else []
-                tu2 = time.perf_counter()
-                self.upload([b[0] for b in bridged] + [b[0] for b in more])
-                tr2 = time.perf_counter()
-                kern = self.run()
-                kernel_end = time.perf_counter() - t0
-                allidx = part + rest
-                got = self.download(out=None if out is None else [out[i] for i in allidx])
-                sols = [None] * n
-                for i, s_ in zip(allidx, got):
-                    sols[i] = s_
-                return sols, {"first_launch": tr2 - t0, "kernels_done": kernel_end, "total": time.perf_counter() - t0,
-                              "streamed": False,
-                              "chunks": [{"worlds": n, "bridge": (tu - tb) + (tu2 - tr), "upload": tr2 - tu2, "kernel": kern}]}
-            hc.set_lane(next_lane)
-            next_lane = (next_lane + max(ng, 1)) % 4
-            hc.run_async()
-            if timing["first_launch"] is None:
-                timing["first_launch"] = time.perf_counter() - t0
-            timing["chunks"].append({"worlds": len(part), "bridge": tu - tb, "upload": tr - tu, "upload_parts": hc.transfer_seconds()})
-            inflight.append((hc, part))
+        try:
+            for c in range(len(fr)):
+                part = idx[cuts[c]:cuts[c + 1]]
+                hc = self.shared(c)
+                tb = time.perf_counter()
+                bridged = interpolate_and_planes_batch_host([items[i] for i in part], veh, parm)
+                tu = time.perf_counter()
+                hc.upload([b[0] for b in bridged])
+                tr = time.perf_counter()
+                # a batch's launch groups run side by side on streams of their own, and kernels that share a stream run one after the
+                # other: deal the four streams out by the group counts (a chunk that comes around to a stream still in use queues
+                # up behind an EARLIER, i.e. smaller, chunk's kernel)
+                ng = len(hc.launch_groups())
+                if c == 0 and (ng > 1 or mixed_by_horizon) and single_launch_if_mixed:
+                    # Several kernel classes (workgroup sizes / residency modes) in the job: their CU shares are balanced per launch,
+                    # and chunks of such launches in flight at once fragment the CUs (measured: map50 set 87 ms streamed against 59 ms,
+                    # room set 115 against 68).  One launch of everything, on this handle, with the rest bridged at once.
+                    rest = idx[cuts[1]:]
+                    more = interpolate_and_planes_batch_host([items[i] for i in rest], veh, parm) if rest else []
+                    tu2 = time.perf_counter()
+                    self.upload([b[0] for b in bridged] + [b[0] for b in more])
+                    tr2 = time.perf_counter()
+                    kern = self.run()
+                    kernel_end = time.perf_counter() - t0
+                    allidx = part + rest
+                    got = self.download(out=None if out is None else [out[i] for i in allidx])
+                    sols = [None] * n
+                    for i, s_ in zip(allidx, got):
+                        sols[i] = s_
+                    return sols, {"first_launch": tr2 - t0, "kernels_done": kernel_end, "total": time.perf_counter() - t0,
+                                  "streamed": False,
+                                  "chunks": [{"worlds": n, "bridge": (tu - tb) + (tu2 - tr), "upload": tr2 - tu2, "kernel": kern}]}
+                hc.set_lane(next_lane)
+                next_lane = (next_lane + max(ng, 1)) % 4
+                hc.run_async()
+                if timing["first_launch"] is None:
+                    timing["first_launch"] = time.perf_counter() - t0
+                timing["chunks"].append({"worlds": len(part), "bridge": tu - tb, "upload": tr - tu, "upload_parts": hc.transfer_seconds()})
+                inflight.append((hc, part))
+        except BaseException:
+            # a chunk failed (an obstacle-heavy world hits CSDO_ELIMIT at its upload, a device allocation fails): the chunks already
+            # launched are still running and their handles are cached on this one - collect them, or every later call on this
+            # handle would find them pending (CSDO_EINVAL at the next upload) with kernels in flight behind the caller's back
+            for hc_, _ in inflight:
+                try:
+                    hc_.wait()
+                except Exception:
+                    pass
+            raise
         sols = [None] * n
         kernel_end = 0.0
         for (hc, part), info in zip(inflight, timing["chunks"]):
@@ -197,11 +215,11 @@ class DsqpHandle:
 
     def launch_groups(self):
         """How the uploaded batch is launched (csdo_dsqp_launch_groups): a list of dicts, one per concurrent kernel."""
-        buf = (abi.LaunchGroup * 8)()
-        n = lib().csdo_dsqp_launch_groups(self._h, buf, 8)
+        buf = (abi.LaunchGroup * 64)()
+        n = lib().csdo_dsqp_launch_groups(self._h, buf, 64)
         if n < 0:
             check(n, "csdo_dsqp_launch_groups")
-        return [{f: getattr(buf[i], f) for f, _ in abi.LaunchGroup._fields_} for i in range(min(n, 8))]
+        return [{f: getattr(buf[i], f) for f, _ in abi.LaunchGroup._fields_} for i in range(min(n, 64))]
 
     def agent_groups(self):
         """Launch group of every agent of the uploaded batch, in upload order (csdo_dsqp_agent_groups)."""

@@ -124,6 +124,27 @@ typedef struct csdo_handle_s* csdo_handle;
 int csdo_dsqp_create(csdo_handle* out, int device_ordinal);
 void csdo_dsqp_destroy(csdo_handle h);
 
+/* The same solver on several GPUs of one node behind ONE handle - the "GPU-count selector" of the boundary.  The reference's
+ * loop over agents (sqp/dsqp_solver.cc:1198-1220) is what shards: an upload cuts the batch's agents (worlds concatenated in
+ * order) into n_devices contiguous blocks of equal estimated work (csdo_dsqp_estimate_work; csdo_dsqp_shard_bounds is the
+ * rule), a block may end inside a world; every device is driven by a host thread of its own through a child handle, and a
+ * download scatters each block straight into the caller's result arrays - no collective: a host caller has no use for one,
+ * and the agents exchange nothing once the planes are fixed.  Results are the bits of the single-device solve.
+ * Work on a multi-device handle: csdo_dsqp_upload / run / run_async / wait / download / solve / solve_batch,
+ * csdo_dsqp_launch_groups and csdo_dsqp_agent_groups (the children's groups one after the other), csdo_dsqp_last_*,
+ * csdo_dsqp_set_min_residency_mode; the single-device entries (bridge, boxes, validator) run on the first device.
+ * csdo_dsqp_run_async(h, stream): every device starts at once on its own streams, `stream` (if given) only joins them.
+ * csdo_dsqp_device_solutions returns NULL for it: a collective wants one buffer per device - csdo_dsqp_multi_child(h, k)
+ * is device k's handle (owned by h; do not destroy it), csdo_dsqp_multi_count(h) their number (0 for a single-device handle).
+ * The same ordinal may be listed twice (two independent batches in flight on one GPU; how the tests run it on one GPU). */
+int csdo_dsqp_create_multi(csdo_handle* out, const int32_t* device_ordinals, int32_t n_devices);
+int32_t csdo_dsqp_multi_count(csdo_handle h);
+csdo_handle csdo_dsqp_multi_child(csdo_handle h, int32_t k);
+/* The sharding rule by itself (host code, no GPU): cuts[0..n_blocks] with block r = items [cuts[r], cuts[r + 1]) of near-equal
+ * total weight - block r ends where the running sum first reaches (r + 1) / n_blocks of the total (the closer of the two candidate
+ * cuts), every block keeps at least one item while there are enough; non-positive total: equal counts. */
+int csdo_dsqp_shard_bounds(const double* weights, int32_t n_items, int32_t n_blocks, int32_t* cuts /* [n_blocks + 1] */);
+
 /* Host-buffer entry: upload, solve on the handle's stream, download.  Replaces the SolverDSQP constructor. */
 int csdo_dsqp_solve(csdo_handle h, const csdo_problem* in, csdo_result* out);
 

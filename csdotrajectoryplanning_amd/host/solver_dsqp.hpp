@@ -46,7 +46,9 @@ class SolverDSQP {
   SolverDSQP(std::vector<std::vector<OptRes>>& solutions, const std::vector<std::vector<OptRes>>& x0_bar,
              const std::vector<std::vector<Plane>>& inter_planes, double dimx, double dimy,
              const ObstacleRange& obstacles, const Parm& param, int logger_level = 2, int device = 0,
-             const csdo_vehicle* vehicle = nullptr) {
+             const csdo_vehicle* vehicle = nullptr, const std::vector<int>& devices = {}) {
+    // devices: several GPU ordinals - the agents are cut into contiguous blocks of equal estimated work, one per device
+    // (csdo_dsqp_create_multi; the loop that shards is sqp/dsqp_solver.cc:1198-1220); empty: the one GPU `device`
     const int Na = (int)x0_bar.size();
     const int Nt = Na ? (int)x0_bar[0].size() : 0;
     std::vector<double> x0((size_t)Na * Nt * 6), obs;
@@ -108,7 +110,8 @@ class SolverDSQP {
     R.admm_iters = admm.data();
     R.last_status = last.data();
     csdo_handle h = nullptr;
-    int rc = csdo_dsqp_create(&h, device);
+    const std::vector<int32_t> devs(devices.begin(), devices.end());
+    int rc = devs.empty() ? csdo_dsqp_create(&h, device) : csdo_dsqp_create_multi(&h, devs.data(), (int32_t)devs.size());
     if (rc == CSDO_OK) rc = csdo_dsqp_solve(h, &P, &R);
     if (h) csdo_dsqp_destroy(h);
     if (rc != CSDO_OK) throw std::runtime_error("csdo_dsqp_solve failed with code " + std::to_string(rc));

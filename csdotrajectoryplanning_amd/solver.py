@@ -61,6 +61,7 @@ class DsqpHandle:
         probs = (abi.Problem * len(worlds))(*[w.c_problem() for w in worlds])
         res = (abi.Result * len(worlds))(*[s._c for s in sols])
         check(lib().csdo_dsqp_solve_batch(self._h, probs, len(worlds), res), "csdo_dsqp_solve_batch")
+        self._keep = list(worlds)          # (the batch stays uploaded: launch_groups / agent_groups / run describe it)
         for s, r in zip(sols, res):
             s._c = r
             s.finish()

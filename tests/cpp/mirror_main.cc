@@ -47,7 +47,7 @@ using namespace libMultiRobotPlanning;
 static bool rd(FILE* f, void* p, size_t n) { return std::fread(p, 1, n, f) == n; }
 
 int main(int argc, char** argv) {
-  if (argc != 3) return 2;
+  if (argc != 3 && argc != 4) return 2;
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 3;
   int32_t hdr[4];   // Na, Nt, n_obs, n_planes
@@ -90,7 +90,15 @@ int main(int argc, char** argv) {
 
   int rc_status = 0;
   try {
-    csdo::SolverDSQP solver(optimize_res, x0_bar, inter_planes, dims[0], dims[1], obstacles, param, /*logger_level*/ 0);
+    // optional third argument: GPU ordinals "0,0" - the same constructor over several devices (csdo_dsqp_create_multi)
+    std::vector<int> devices;
+    if (argc > 3)
+      for (const char* p = argv[3]; *p;) {
+        devices.push_back((int)std::strtol(p, const_cast<char**>(&p), 10));
+        if (*p == ',') ++p;
+      }
+    csdo::SolverDSQP solver(optimize_res, x0_bar, inter_planes, dims[0], dims[1], obstacles, param, /*logger_level*/ 0,
+                            /*device*/ 0, /*vehicle*/ nullptr, devices);
     FILE* o = std::fopen(argv[2], "wb");
     if (!o) return 5;
     const int32_t st[2] = {solver.getSolverStatus(), solver.get_initial_static_legal() ? 1 : 0};

@@ -24,7 +24,8 @@ def test_cpp_mirror_compiles_against_reference_shaped_types():
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path, devices):
     _build()
     veh, parm = veh_parm
     w, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
@@ -41,7 +42,8 @@ def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path):
             f.write(struct.pack("<i", int(p["t"])))
             f.write(np.ascontiguousarray(p["c"], dtype=np.float64).tobytes())
         f.write(np.ascontiguousarray(w.obstacles).tobytes())
-    r = subprocess.run([BIN, fin, fout], capture_output=True, text=True, timeout=300)
+    # devices "0,0": the same constructor with a device list - two child handles on the one GPU, agents split between them
+    r = subprocess.run([BIN, fin, fout] + ([devices] if devices else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     raw = open(fout, "rb").read()
     status, legal = struct.unpack_from("<2i", raw, 0)

@@ -195,7 +195,7 @@ def test_full_chain_against_oracle_with_acceptance(gpu_handle, oracle, workload)
     # and the objective, evaluated in numpy on both results.  Agents within 1e-4 of the oracle: the same verdict unless a
     # residual sits within 1e-3 of its threshold, the same objective to 1e-3; the outliers: listed above.
     first = np.cumsum([0] + [w.Na for w in worlds])
-    n_verdicts = 0
+    n_verdicts = n_whole = 0
     for k, (w, g, r) in enumerate(zip(worlds, got, ref)):
         close = d[first[k]:first[k + 1]] <= parity.TOL
         fg, fr = results.feasibility(w, g.solutions), results.feasibility(w, r.solutions)
@@ -205,23 +205,23 @@ def test_full_chain_against_oracle_with_acceptance(gpu_handle, oracle, workload)
         assert np.all((ok_g == ok_r) | borderline | ~close), (k, np.nonzero(ok_g != ok_r)[0])
         both = (g.last_status == 1) & (r.last_status == 1) & close
         np.testing.assert_allclose(fg["objective"][both], fr["objective"][both], rtol=1e-3, atol=1e-4)
-        vg = results.validate(g.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
-        vr = results.validate(r.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
-        # the authors' acceptance of a result (scripts/collision_detection.py): a world all of whose agents are within 1e-4 of the
-        # oracle gets the same verdicts, vehicle against vehicle and vehicle against obstacle, to the collision count - unless the
-        # oracle's own result is within 1e-3 of touching (then a count may differ by a frame or two); a world with a chain outlier
-        # (listed above) may differ
-        if close.all():
+        # the authors' acceptance of a result (scripts/collision_detection.py), on the agents of the world that are within 1e-4 of the
+        # oracle (all of them in a world without a listed outlier; the 100-vehicle set has an outlier in every world): the same
+        # verdicts, vehicle against vehicle and vehicle against obstacle, to the collision count - unless the oracle's own result
+        # is within 1e-3 of touching (then a count may differ by a frame or two)
+        if close.sum() >= 2:
+            vg = results.validate(g.solutions[close], w.veh, w.obstacles, w.dimx, w.dimy)
+            vr = results.validate(r.solutions[close], w.veh, w.obstacles, w.dimx, w.dimy)
             near_touch = abs(vr.min_obstacle_clearance) < 1e-3
             assert (vg.obstacle_collisions == 0) == (vr.obstacle_collisions == 0) or near_touch, (k, vg, vr)
             assert (vg.vehicle_collisions == 0) == (vr.vehicle_collisions == 0), (k, vg.vehicle_collisions, vr.vehicle_collisions)
             assert abs(vg.vehicle_collisions - vr.vehicle_collisions) <= 2 and abs(vg.obstacle_collisions - vr.obstacle_collisions) <= 2, (k, vg, vr)
             n_verdicts += 1
+            n_whole += int(close.all())
         assert g.initial_static_legal == r.initial_static_legal
-    # worlds without any outlier, from the committed list: every one of them had its verdicts compared
-    clean = len(worlds) - len({w for w, _ in listed})
-    print(workload, "worlds whose collision verdicts were compared (all agents within 1e-4):", n_verdicts, "of", len(worlds))
-    assert n_verdicts == clean and clean >= {"map100": 30, "map50": 60, "room50": 1, "agents100": 1}[workload], (n_verdicts, clean)
+    clean = len(worlds) - len({w for w, _ in listed})      # worlds without any listed outlier: compared whole
+    print(workload, "worlds whose collision verdicts were compared:", n_verdicts, "of", len(worlds), "- whole worlds:", n_whole)
+    assert n_verdicts == len(worlds) and n_whole == clean, (n_verdicts, n_whole, clean)
 
 
 def test_synthetic_1024_batch(gpu_handle, oracle):

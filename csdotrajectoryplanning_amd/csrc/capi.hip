@@ -244,6 +244,18 @@ static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds);
 // ---------------------------------------------------------------------------------------------------------------------
 // Several GPUs behind one handle (csdo_dsqp_create_multi)
 // ---------------------------------------------------------------------------------------------------------------------
+// CSDO_ELIMIT from the packing: a horizon beyond CSDO_MAX_NT (one lane per timestep; the reference has no cap,
+// sqp/inter_agent_cons.cc:320-325).  csdo_dsqp_last_limit then names that world (agent 0; no LDS figure: 0 bytes).
+static void note_horizon_limit(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
+  for (int w = 0; worlds && w < n_worlds; ++w)
+    if (worlds[w].Nt > CSDO_MAX_NT) {
+      h->limit_world = w;
+      h->limit_agent = 0;
+      h->limit_bytes = 0;
+      return;
+    }
+}
+
 // Contiguous blocks [cuts[r], cuts[r + 1]) of near-equal total weight: block r ends where the running sum first reaches
 // (r + 1) / n_blocks of the total - the closer of the two candidate cuts -, every block keeps at least one item while there are
 // enough (the rule of sharding.py: shard_bounds_weighted, which the N-process path uses; tests/test_multi_host.py holds them equal).
@@ -325,6 +337,7 @@ static int multi_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_wor
   const double t0 = now_s();
   HostBatch all;   // validates the batch and yields the per-agent work estimate (csdo_dsqp_estimate_work's)
   int rc = pack_worlds(worlds, n_worlds, all);
+  if (rc == CSDO_ELIMIT) note_horizon_limit(h, worlds, n_worlds);
   if (rc != CSDO_OK) return rc;
   const int nk = (int)M.kids.size(), Na = (int)all.agents.size();
   std::vector<double> est((size_t)Na);
@@ -682,6 +695,7 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   h->limit_bytes = 0;
   const double t0 = now_s();
   int rc = pack_worlds(worlds, n_worlds, h->hb);
+  if (rc == CSDO_ELIMIT) note_horizon_limit(h, worlds, n_worlds);
   if (rc != CSDO_OK) return rc;
   HostBatch& hb = h->hb;
   const size_t Na = hb.agents.size();

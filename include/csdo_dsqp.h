@@ -155,7 +155,8 @@ int csdo_dsqp_solve(csdo_handle h, const csdo_problem* in, csdo_result* out);
 int csdo_dsqp_solve_batch(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds, csdo_result* results);
 /* After a CSDO_ELIMIT from an upload / solve: the first world (index in the batch) and agent (index in that world) whose
  * working set fits no residency mode, and the dynamic LDS it would need (limit: 160 KB - 64 B).  One such world rejects the
- * whole batch - nothing is launched -; drop it and call again.  -1 / -1 if the last upload did not hit the limit. */
+ * whole batch - nothing is launched -; drop it and call again.  A world whose horizon exceeds CSDO_MAX_NT is named the same way
+ * (agent 0, 0 bytes).  -1 / -1 if the last upload did not hit the limit. */
 int csdo_dsqp_last_limit(csdo_handle h, int32_t* world, int32_t* agent, int64_t* lds_bytes_needed);
 
 /* Split-phase form used by bench.py so the timed region starts with inputs resident in HBM:

@@ -120,3 +120,24 @@ def test_two_handles_driven_by_two_host_threads(gpu_handle):
         assert len(out[k]) == len(jobs[k])
         for sel, sols in out[k]:
             assert all(_same(s, ref[i]) for i, s in zip(sel, sols)), (k, sel)
+
+
+def test_a_chunk_that_fails_leaves_the_handle_usable(gpu_handle):
+    """The second chunk of a streamed job hits CSDO_ELIMIT at its upload (a world with more obstacles than fit LDS): the first
+    chunk's kernels are already in flight on a cached child handle.  do_phase_stream collects them before it re-raises, so the
+    same handle streams the next job (it used to fail with CSDO_EINVAL until the handle was closed)."""
+    from csdotrajectoryplanning_amd._lib import CsdoError
+    items, worlds = _items_and_worlds("map100", 4)
+    ref = gpu_handle.solve_batch(worlds)
+    rng = np.random.default_rng(1)
+    walls = np.column_stack([rng.uniform(300, 400, 7000), rng.uniform(300, 400, 7000), np.full(7000, 0.5)])
+    bad = list(items)
+    bad[3] = (*items[3][:4], 500.0, 500.0, walls)        # the last world: it is in the last chunk
+    with pytest.raises(CsdoError) as e:
+        gpu_handle.do_phase_stream(bad, worlds[0].veh, worlds[0].parm, min_first_agents=0)
+    assert "-4" in str(e.value)
+    for c in gpu_handle._children.values():              # nothing is pending on any of the chunk handles
+        with pytest.raises(CsdoError):
+            c.wait()
+    got, tm = gpu_handle.do_phase_stream(items, worlds[0].veh, worlds[0].parm, min_first_agents=0)
+    assert tm["streamed"] is True and all(_same(g, r) for g, r in zip(got, ref))

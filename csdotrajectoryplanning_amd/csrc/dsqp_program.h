@@ -957,6 +957,47 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
   return (success ? 1 : 0) | (initial << 1);
 }
 
+// A box at one call site of the agent program.  CSDO_BOX_CALL (device build only): a REAL call - the box code (cull, the four stop
+// events, the replay, the repair of a point inside an obstacle) is the largest cold piece of the program and was inlined four
+// times, twice per role; as a call there is one copy, and the LDS arrays it reads (the obstacle list, the cache of step counts)
+// are rebuilt inside the callee from their offsets in the workgroup's dynamic LDS, so that they stay ds_* accesses (an LDS
+// pointer passed through an argument has lost its address space).  Same bits either way.  CSDO_BOX_CALL is a mask: 1 = the row
+// role's sites (front discs), 2 = the solver role's (rear discs).
+struct BoxOut {
+  double x_min, y_min, x_max, y_max;
+  int status;
+};
+#if !defined(CSDO_BOX_CALL)
+#define CSDO_BOX_CALL 0
+#endif
+#if CSDO_BOX_CALL && defined(CSDO_LANE_MODE_DEVICE)
+__device__ __noinline__ BoxOut make_box_call(const double x, const double y, const int obs_off, const int n_obs, const double dimx,
+                                             const double dimy, const double rv, const int cache_off, const int cache_stride,
+                                             const int cache_cap) {
+  extern __shared__ __align__(16) double csdo_lds_base[];
+  BoxD b{0, 0, 0, 0};
+  const BoxCache ec{(unsigned*)csdo_lds_base + cache_off, cache_stride, cache_cap};
+  const int st = make_box(x, y, csdo_lds_base + obs_off, n_obs, dimx, dimy, rv, b, ec);
+  return BoxOut{b.x_min, b.y_min, b.x_max, b.y_max, st};
+}
+template <bool CALL>
+CSDO_FN int box_at(const double x, const double y, const double* obs, const int n_obs, const double dimx, const double dimy,
+                   const double rv, BoxD& res, const BoxCache& ec) {
+  if constexpr (!CALL) return make_box(x, y, obs, n_obs, dimx, dimy, rv, res, ec);
+  extern __shared__ __align__(16) double csdo_lds_base[];
+  const int obs_off = uniform_i32((int)(obs - (const double*)csdo_lds_base));
+  const BoxOut o = make_box_call(x, y, obs_off, n_obs, dimx, dimy, rv, (int)(ec.base - (unsigned*)csdo_lds_base), ec.stride, ec.cap);
+  res = BoxD{o.x_min, o.y_min, o.x_max, o.y_max};
+  return o.status;
+}
+#else
+template <bool CALL>
+CSDO_FN int box_at(const double x, const double y, const double* obs, const int n_obs, const double dimx, const double dimy,
+                   const double rv, BoxD& res, const BoxCache& ec) {
+  return make_box(x, y, obs, n_obs, dimx, dimy, rv, res, ec);
+}
+#endif
+
 // =========================================================================================================
 // 6x6 dense helpers (all indices compile-time so everything stays in registers)
 // =========================================================================================================

@@ -785,7 +785,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     const double spy = scp_.s, cpy = scp_.c;
     const double xr = (double)(float)(px + P.r2x * cpy), yr = (double)(float)(py + P.r2x * spy);
     BoxD br;
-    const int sr = make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
+    const int sr = box_at<(CSDO_BOX_CALL & 2) != 0>(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
     CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
     CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
     SU(n_block_fields - 1, t) = ((sr >> 1) > 0) ? 1.0 : 0.0;
@@ -797,7 +797,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     const double spy = scp_.s, cpy = scp_.c;
     const double xf = (double)(float)(px + P.f2x * cpy), yf = (double)(float)(py + P.f2x * spy);
     BoxD bf;
-    const int sf = make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
+    const int sf = box_at<(CSDO_BOX_CALL & 1) != 0>(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
     CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
     CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
     SU(n_block_fields - 2, t) = ((sf >> 1) > 0) ? 1.0 : 0.0;
@@ -2531,7 +2531,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double spy = scp_.s, cpy = scp_.c;
         const double xr = px + P.r2x * cpy, yr = py + P.r2x * spy;
         BoxD br;
-        make_box(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
+        box_at<(CSDO_BOX_CALL & 2) != 0>(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
         CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
         CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
       }
@@ -2543,7 +2543,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double spy = scp_.s, cpy = scp_.c;
         const double xf = px + P.f2x * cpy, yf = py + P.f2x * spy;
         BoxD bf;
-        make_box(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
+        box_at<(CSDO_BOX_CALL & 1) != 0>(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
         CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
         CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
       }

@@ -14,7 +14,7 @@ import tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "csdotrajectoryplanning_amd", "csrc")
 block, mode = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("512", "0")
-out = os.path.join(tempfile.gettempdir(), "csdo_variant_%s_%s.s" % (block, mode))
+out = os.path.join(tempfile.gettempdir(), "csdo_variant_%s_%s%s.s" % (block, mode, os.environ.get("CSDO_ASM_TAG", "")))
 extra = ["-DCSDO_ASM_MARKS"] if os.environ.get("CSDO_ASM_MARKS") else []
 cmd = ["/opt/rocm/bin/hipcc", *os.environ.get("CSDO_XFLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
        "-DCSDO_V_BLOCK=" + block, "-DCSDO_V_MODE=" + mode, "-DCSDO_V_SPLIT=1", "-S", "--cuda-device-only", *extra,

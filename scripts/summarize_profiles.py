@@ -66,7 +66,7 @@ for f in find("trace/**/*kernel_trace.csv"):
             summary["ms_per_step"] = sum(step_spans) / len(step_spans)
             summary["steps_in_trace"] = len(steps)
 pmc = {}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "tcc", "tcc2"):
     for f in find("%s/**/*counter_collection.csv" % sub):
         per = {}
         with open(f) as fh:
@@ -101,6 +101,13 @@ if g("SQ_WAVE_CYCLES"):
         # upper bound of the fp64 issue utilisation: every VALU wave-instruction priced as a 4-cycle fp64 issue slot on one
         # of the 1024 SIMDs at 2.4 GHz
         summary["valu_fp64_issue_frac"] = g("SQ_INSTS_VALU") * 4.0 / (1024.0 * 2.4e9 * summary["ms_per_step"] * 1e-3)
+if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
+    # the guide's L2 hit rate; every request that misses goes to the Infinity Cache / HBM (a 2 - 3 k cycle trip for a dependent load)
+    summary["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    summary["l2_misses_per_launch"] = g("TCC_MISS_sum")
+if g("TCP_TCC_READ_REQ_sum") and g("TCC_EA0_RDREQ_sum") is not None:
+    summary["l2_read_requests_per_launch"] = g("TCP_TCC_READ_REQ_sum")
+    summary["fabric_read_requests_over_l2_read_requests"] = g("TCC_EA0_RDREQ_sum") / g("TCP_TCC_READ_REQ_sum")
 summary["_note"] = ("rocprofv3 --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE in separate passes), command: python3 "
                     "bench.py --workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --setup-procs 1 --skip-single-instance; "
                     "per_step = sum over the dsqp_agent_kernel dispatches / 4 steps" % wl)

@@ -32,6 +32,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   const int st = 2 * ((ad_Nt + 1) >> 1);
   Shm sh;
   sh.stride = st;
+  sh.wave0 = uniform_i32((int)threadIdx.x & ~63);
   sh.vec = aligned16(lds);
   sh.pl = sh.vec;       // aliases, see Shm
   sh.pr = aligned16(sh.vec + 6 * st);

@@ -64,43 +64,64 @@ __device__ __forceinline__ double csdo_one_if(const bool c, const double d) {
   const unsigned lo = c ? 0u : (unsigned)u, hi = c ? one_hi : (unsigned)(u >> 32);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-#define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = csdo_opaque((int)threadIdx.x); t < Nt)
+// The thread's index in the workgroup WITHOUT its work-item id register: wave base (a block-uniform value per wave, Shm::wave0: a
+// scalar register) + lane number (v_mbcnt: two vector instructions).  As `threadIdx.x` the index lived in v0 for the whole program,
+// i.e. it was spilled, and every lanes-block of the cold phases began with a scratch round trip for it - load, wait, compare with
+// Nt - before its first useful access (six per Ruiz pass, hundreds per SQP iteration).  CSDO_TID recomputes it where it is asked for
+// (volatile: neither hoisted nor kept across blocks - the same job the empty asm of csdo_opaque did for the old form);
+// CSDO_TID_HOT is the plain expression, which the compiler may keep in a register across a block of ADMM iterations.
+#if !defined(CSDO_TID_MBCNT)
+#define CSDO_TID_MBCNT 1
+#endif
+#if CSDO_TID_MBCNT
+__device__ __forceinline__ int csdo_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+#define CSDO_TID (sh.wave0 + csdo_lane_id())
+#define CSDO_TID_HOT (sh.wave0 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#else
+#define CSDO_TID csdo_opaque((int)threadIdx.x)
+#define CSDO_TID_HOT ((int)threadIdx.x)
+#endif
+#define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = CSDO_TID; t < Nt)
 // ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
 #define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
 #define CSDO_SLANES(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0 && t < Nt)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = CSDO_TID - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
 // tail lanes: solver threads [base, base + n_tail), independent of Nt (n_tail <= 36)
 #define CSDO_TLANES(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0 && t < n_tail)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = CSDO_TID - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
 // every thread of the solver half, whatever Nt (element-parallel work: t in [0, nthr))
 #define CSDO_STHREADS(t, nthr)                                                              \
   if constexpr (ROLE != ROLE_ROW)                                                           \
     if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
-      if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0)
+      if (const int t = CSDO_TID - CSDO_SOLVER_BASE; t >= 0)
 // blocks of the ADMM iteration keep the plain lane index: their addresses are few and live in registers for the whole
 // block of iterations
-#define CSDO_LANES_HOT(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = (int)threadIdx.x; t < Nt)
+#define CSDO_LANES_HOT(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = CSDO_TID_HOT; t < Nt)
 #define CSDO_SLANES_HOT(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = CSDO_TID_HOT - CSDO_SOLVER_BASE; t >= 0 && t < Nt)
 #define CSDO_TLANES_HOT(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = CSDO_TID_HOT - CSDO_SOLVER_BASE; t >= 0 && t < n_tail)
 // the same 36 lanes taken from the LAST wave of the workgroup: with Nt <= BLOCK/2 - 64 that wave owns no timestep, so what it
 // does runs beside the other solver waves' work instead of in front of it
 #define CSDO_TLANES_TOP(t) \
-  if constexpr (ROLE != ROLE_ROW) if (const int t = (int)threadIdx.x - ((int)blockDim.x - 64); t >= 0 && t < n_tail)
+  if constexpr (ROLE != ROLE_ROW) if (const int t = CSDO_TID_HOT - ((int)blockDim.x - 64); t >= 0 && t < n_tail)
 #define CSDO_STHREADS_HOT(t, nthr)                                                          \
   if constexpr (ROLE != ROLE_ROW)                                                           \
     if (const int nthr = (ROLE == ROLE_BOTH) ? (int)blockDim.x : (int)(blockDim.x >> 1); true) \
-      if (const int t = (int)threadIdx.x - CSDO_SOLVER_BASE; t >= 0)
+      if (const int t = CSDO_TID_HOT - CSDO_SOLVER_BASE; t >= 0)
 // Pair-split solve (agent_program, residency modes 0 and 1): EVERY thread of the solver half takes part, whatever Nt - the
 // cross-lane moves below need whole waves.  A block of such lanes is a sequence of steps; what one step hands to other lanes
 // (through the DPP moves of CSDO_XGET or through LDS) is read in the next one.  On the device the steps are straight-line code of
 // one wave (lock step; LDS instructions of a wave complete in order, so an in-wave exchange through LDS needs no barrier); the
 // lane-serial build closes the loop over the lanes at every CSDO_XSTEP and opens the next one.
-#define CSDO_XLANES(t) if constexpr (ROLE != ROLE_ROW) if (const int t = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE); t >= 0)
+#define CSDO_XLANES(t) if constexpr (ROLE != ROLE_ROW) if (const int t = CSDO_TID - CSDO_SOLVER_BASE; t >= 0)
 // lanes 0..5 of every solver wave behind which another wave starts at node s (< Nt): one component q each (sum of the partials that node takes from this wave)
 #define CSDO_HANDOVER_LANES(s, q) \
-  if constexpr (ROLE != ROLE_ROW) if (const int tt_ = csdo_opaque((int)threadIdx.x - CSDO_SOLVER_BASE), q = tt_ & 63, s = tt_ - q + 64; tt_ >= 0 && q < 6 && s < Nt)
+  if constexpr (ROLE != ROLE_ROW) if (const int tt_ = CSDO_TID - CSDO_SOLVER_BASE, q = tt_ & 63, s = tt_ - q + 64; tt_ >= 0 && q < 6 && s < Nt)
 #define CSDO_XSTEP(t)               /* register hand-over (DPP): program order is all it needs */
 #define CSDO_XSTEP_LDS(t) csdo_wave_sync();   /* in-wave hand-over through LDS */
 __device__ __forceinline__ void csdo_wave_sync() {   // orders the wave's own LDS stores before its later LDS loads for the compiler
@@ -459,6 +480,7 @@ struct Shm {
                     // were an HBM round trip in every iteration's plane pass)
   int n_pco, n_pco_ld;
   int stride;
+  int wave0;        // device: index of the wave's first thread in the workgroup (block-uniform per wave; see CSDO_TID)
 };
 
 struct AgentCtx {
@@ -520,7 +542,7 @@ template <int K, bool IS_SUM>
 CSDO_FN void red_fold(const Shm& sh, int Nt, double (&out)[K]) {
   CSDO_SYNC();
 #if defined(CSDO_LANE_MODE_DEVICE)
-  const int tid = (int)threadIdx.x;
+  const int tid = CSDO_TID;
   if constexpr (!IS_SUM && K > 2) {
     static_assert(K <= 16, "one 16-lane row per segment");
     if (tid < 64) {
@@ -593,7 +615,7 @@ CSDO_FN void lds_max_nonneg(double* addr, double v) {
 CSDO_FN void field_sum(const Shm& sh, int Nt, int k, double (&out)[1]) {
   const double* f = sh.vec + (size_t)k * (size_t)sh.stride;
 #if defined(CSDO_LANE_MODE_DEVICE)
-  const int tid = (int)threadIdx.x;
+  const int tid = CSDO_TID;
   if (tid < 64) {
     double acc = 0.0;
     for (int j = tid; j < Nt; j += 64) acc = acc + f[j];

@@ -771,7 +771,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #if defined(CSDO_LANE_MODE_DEVICE)
   // (all but the last two fields of them: those carry the initial boxes' status flags, written while other lanes still grow)
   const int box_cap_ = (int)(((size_t)(n_block_fields - 2) * (size_t)sh.stride * 2) / (size_t)blockDim.x);
-  const BoxCache box_cache{(unsigned*)sh.vec + threadIdx.x, (int)blockDim.x, box_cap_ < 32 ? box_cap_ : 32};
+  const BoxCache box_cache{(unsigned*)sh.vec + CSDO_TID, (int)blockDim.x, box_cap_ < 32 ? box_cap_ : 32};
 #else
   unsigned box_words_[32];
   const BoxCache box_cache{box_words_, 1, 32};
@@ -843,6 +843,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     double* const fx_lds = (MODE == 0) ? lds_ptr(sh.fx) : nullptr;
 #define RZ(r, f_lds, f_ws) (*(L ? &fx_lds[(f_lds) * csdo_opaque_s((int)rcap) + (r)] : &ROW(r, f_ws)))   /* f_lds: a, b, c_yaw, E, u */
 #define RZ_TIME(pl_) (L ? (int)fx_lds[5 * csdo_opaque_s((int)rcap) + (pl_)] : (int)planes[pl_].t)
+#define DACC(j, t) (*((MODE == 3) ? &CD(C_D + (j), t) : &SU(30 + (j), t)))
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       double dfx, dfy, drx, dry, exf, eyf, exr, eyr;
@@ -850,8 +851,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       SU(14, t) = dfx; SU(15, t) = dfy; SU(16, t) = drx; SU(17, t) = dry;
       SU(18, t) = exf; SU(19, t) = eyf; SU(20, t) = exr; SU(21, t) = eyr;
       SU(10, t) = 0.0; SU(11, t) = 0.0; SU(12, t) = 0.0;
-      // the accumulated column scaling D lives in the workspace (six accumulators less in the registers of the passes)
-      CSDO_FOR(j, 6, { CD(C_D + j, t) = 1.0; });
+      // the accumulated column scaling D: six accumulators less in the registers of the passes.  In LDS (fields 30..35 of the idle
+      // block arrays) where the mode has them - read, multiplied and written back where a pass has its column factors, no trip to
+      // the workspace and nothing held across the pass -, in the workspace for the lean mode 3 (30 fields); published after the
+      // last pass (warm start)
+      CSDO_FOR(j, 6, { DACC(j, t) = 1.0; });
       // the (unscaled) bounds wait in the workspace until the warm start: 32 doubles less in the equilibration's registers
       CSDO_FOR(i, NROW, {
         WS(W_LO + i, t) = S.lo[i];
@@ -924,8 +928,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       CSDO_LANES(t) {
         LaneState& S = CSDO_LS(t);
         double cn_[6] = {0, 0, 0, 0, 0, 0};  // column norms of [P; A]
-        double dacc[6];                      // accumulated column scaling so far (fetched early: the row factors hide the trip)
-        CSDO_FOR(j, 6, { dacc[j] = CD(C_D + j, t); });
         double* Dt = S.b;                    // scratch: per-column factor of this pass
         double* Et = S.z;                    // scratch: per-row factor of this pass
         if (t > 0) {
@@ -944,17 +946,17 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(q, 4, { eacc[q] = SU(14 + 4 * grp + q, t); });   // (in flight while the group's factors are computed)
           CSDO_FOR(q, 4, {
             constexpr int i = 4 * grp + q;
+            // (no test whether the row exists at this t: the coefficients of a row that does not are zero - its norm is 0, its
+            //  factor 1, the column maxima unchanged -, and sixteen tests were sixteen basic blocks, each waiting for its own operands)
             double rn = 0.0;
-            if (S.act & (1u << i)) {
-              CSDO_FOR(s, 3, {
-                if constexpr (row_col(i, s) >= 0) {
-                  const double a = fabs(S.c[i][s]);
-                  rn = nmax(rn, a);
-                  cn_[row_col(i, s)] = nmax(cn_[row_col(i, s)], a);
-                }
-              });
-              if constexpr (i < 4) rn = nmax(rn, fabs(S.cn[i]));
-            }
+            CSDO_FOR(s, 3, {
+              if constexpr (row_col(i, s) >= 0) {
+                const double a = fabs(S.c[i][s]);
+                rn = nmax(rn, a);
+                cn_[row_col(i, s)] = nmax(cn_[row_col(i, s)], a);
+              }
+            });
+            if constexpr (i < 4) rn = nmax(rn, fabs(S.cn[i]));
             ln[q] = limit_norm(rn);
           });
           CSDO_FOR(q, 4, { e4[q] = inv_sqrt_limited(ln[q]); });
@@ -989,7 +991,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         });
         S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
         S.Pww = (S.Pww * Dt[5]) * Dt[5];
-        CSDO_FOR(j, 6, { CD(C_D + j, t) = dacc[j] * Dt[j]; });
+        {
+          double dacc[6];
+          CSDO_FOR(j, 6, { dacc[j] = DACC(j, t); });
+          CSDO_FOR(j, 6, { DACC(j, t) = dacc[j] * Dt[j]; });
+        }
       }
       CSDO_SYNC();
       CSDO_SUB(1);
@@ -1083,7 +1089,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       WS(W_LOOSE, t) = (double)loose;
       // osqp_warm_start_x: x <- Dinv x0
       CSDO_FOR(j, 6, {
-        S.x[j] = (1.0 / CD(C_D + j, t)) * CD(C_SOL0 + j, t);
+        const double dj = DACC(j, t);
+        if constexpr (MODE != 3) CD(C_D + j, t) = dj;   // (the master copy: read by the residual update and the SQP bookkeeping)
+        S.x[j] = (1.0 / dj) * CD(C_SOL0 + j, t);
       });
       CSDO_FOR(k, 4, { SU(5 + k, t) = S.x[k]; });
     }
@@ -1320,7 +1328,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #else
       if constexpr (ROLE == ROLE_ROW) {
 #endif
-        const int x = (int)threadIdx.x, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
+        const int x = CSDO_TID_HOT, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
         if (x < 128) {
           double a0 = 0.0, a1 = 0.0;
           if (wl < 63 && r < n_tail) {
@@ -1580,7 +1588,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       // (Not in the 1024-thread class, residency mode 3: with 128 registers per lane the extra code costs its row waves more
       //  than the product takes on the solver wave - room50's long-horizon agents: 91.9 -> 88.0 ms.)
       if constexpr (ROLE == ROLE_ROW && MODE < 2) {
-        const int x = (int)threadIdx.x, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
+        const int x = CSDO_TID_HOT, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
         if (x < 128) {
           double a0 = 0.0, a1 = 0.0;
           if (wl < 63 && r < n_tail) {
@@ -2570,7 +2578,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     for (int k = 0; k < 6; ++k) B.prof[(int64_t)agent * 48 + 40 + k] = sub_acc[k];
   }
   if constexpr (ROLE == ROLE_SOLVER) {
-    const int ts = (int)threadIdx.x - (int)(blockDim.x >> 1);
+    const int ts = CSDO_TID - (int)(blockDim.x >> 1);
     if (B.prof && ts > 0 && ts < Nt && (ts & (ts - 1)) == 0) {   // lanes 1, 2, 4, ...: eliminated at level log2(ts)
       int lv = 0;
       while ((1 << lv) < ts) ++lv;

@@ -294,11 +294,16 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           if (g < G && t < Nt) {
             const bool has_r = (t + h) < Nt;
             const size_t st_ = (size_t)csdo_opaque_s(sh.stride);
-            const double* const sv_ = sh.vec + 36 * st_ + (unsigned)t;
 #define SV(k) sv_[(size_t)(k) * st_]
+            // (t, base: taken through an empty asm inside each column's trip - the dozen-odd 32-bit offsets of this block's accesses
+            //  (XC at t, base and t + h, the two factor slots, the couplings of two nodes) were otherwise formed in front of the column
+            //  loop, spilled, and came back from scratch one by one, each waited for in front of its use: ten round trips per column)
+            const int t_o = t, base_o = base;
             {
               int cc = 0;
               do {
+                const int t = csdo_keep(t_o), base = csdo_keep(base_o);
+                const double* const sv_ = sh.vec + 36 * st_ + (unsigned)t;   // (the pivot inverse's 21 field addresses: formed in the trip that uses them)
                 const int c = g * per + cc;
                 double rlc[6], tc[6];
                 CSDO_FOR(k, 6, { rlc[k] = FR(k * 6 + c, base); });
@@ -327,6 +332,8 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
             if (has_r) {
               int cc = 0;
               do {
+                const int t = csdo_keep(t_o), base = csdo_keep(base_o);
+                const double* const sv_ = sh.vec + 36 * st_ + (unsigned)t;
                 const int c = g * per + cc;
                 double tc[6], rrc[6], vc[6];
                 CSDO_FOR(k, 6, { tc[k] = XC(k * 6 + c, t); });

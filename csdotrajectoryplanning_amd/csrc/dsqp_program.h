@@ -29,6 +29,15 @@
 
 #include "csdo_device_types.h"
 
+// experiment switches of round 5 (each measured with old and new library interleaved on one box, scripts/gpu_ab.sh)
+#if !defined(CSDO_ABSORB_BY_NEIGHBOUR)
+#define CSDO_ABSORB_BY_NEIGHBOUR 1   // mode 0 factorisation: the eliminated node's lane copies the survivor's new coupling out of LDS
+#endif
+#if !defined(CSDO_TS_LDS)
+#define CSDO_TS_LDS 0                // modes 0, 1: a timestep's plane range in LDS (carry's spare doubles) instead of lane state: the rhs assembly loses its
+                                     // two scratch reloads and the step gets SLOWER (map100 57.99 -> 58.63 ms): the reloads were hidden, the LDS reads are not
+#endif
+
 #if defined(CSDO_LANE_MODE_DEVICE)
 #include <hip/hip_runtime.h>
 #define CSDO_FN __device__ __forceinline__
@@ -69,7 +78,7 @@ __device__ __forceinline__ double csdo_one_if(const bool c, const double d) {
 // i.e. it was spilled, and every lanes-block of the cold phases began with a scratch round trip for it - load, wait, compare with
 // Nt - before its first useful access (six per Ruiz pass, hundreds per SQP iteration).  CSDO_TID recomputes it where it is asked for
 // (volatile: neither hoisted nor kept across blocks - the same job the empty asm of csdo_opaque did for the old form);
-// CSDO_TID_HOT is the plain expression, which the compiler may keep in a register across a block of ADMM iterations.
+// CSDO_TID_HOT (the blocks of the ADMM iteration) is the same.
 #if !defined(CSDO_TID_MBCNT)
 #define CSDO_TID_MBCNT 1
 #endif
@@ -80,7 +89,14 @@ __device__ __forceinline__ int csdo_lane_id() {
   return l;
 }
 #define CSDO_TID (sh.wave0 + csdo_lane_id())
+#if !defined(CSDO_TID_HOT_VOLATILE)
+#define CSDO_TID_HOT_VOLATILE 0   /* 1: recomputed in the iteration's blocks too - no scratch reload at the head of the update, and slower (57.99 -> 58.42 ms) */
+#endif
+#if CSDO_TID_HOT_VOLATILE
+#define CSDO_TID_HOT CSDO_TID   /* (as a plain expression it was computed once, spilled, and reloaded - with a full wait - at the head of every update) */
+#else
 #define CSDO_TID_HOT (sh.wave0 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#endif
 #else
 #define CSDO_TID csdo_opaque((int)threadIdx.x)
 #define CSDO_TID_HOT ((int)threadIdx.x)

@@ -523,8 +523,26 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
     CSDO_SYNC();
     CSDO_FPHASE(19);
-    CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements and take the coupling to their new right neighbour
-      if constexpr (MODE == 0) {   // (beside them, the eliminated nodes move F_r = V' from their LDS column to its place)
+    if constexpr (MODE == 0 && CSDO_ABSORB_BY_NEIGHBOUR) {
+      // The eliminated nodes' lanes (idle otherwise) move what sits in LDS columns to its place in the workspace: their own
+      // F_r = V', and - for the surviving node on their left - the coupling to its new right neighbour (fields 42..77 of THAT node's
+      // column).  The survivor's lane did that copy itself, in the middle of its work on the diagonal block: five entries of the
+      // block sat in scratch while the 36 stores went out and came back one by one behind full waits.  A block of its own, in front
+      // of the survivors': they overwrite fields 36..56 of their column with the next level's pivot inverse (node and lane are at
+      // most 32 apart and in one aligned group of 64: one wave, program order).
+      CSDO_SLANES(t) {
+        if ((t & m2) == h) {
+          if ((t + h) < Nt) {
+            CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = XC(r * 6 + c, t); }); });
+            CSDO_FOR(k, 36, { FR(k, t - h) = XC(42 + k, t - h); });
+          } else {
+            CSDO_FOR(k, 36, { FR(k, t - h) = 0.0; });
+          }
+        }
+      }
+    }
+    CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements (and, but for mode 0, take the coupling to their new right neighbour)
+      if constexpr (MODE == 0 && !CSDO_ABSORB_BY_NEIGHBOUR) {   // (beside them, the eliminated nodes move F_r = V' from their LDS column to its place)
         if ((t & m2) == h && (t + h) < Nt) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = XC(r * 6 + c, t); }); });
       }
       if ((t & m2) == 0) {
@@ -534,13 +552,15 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
           if (t >= h) CSDO_FOR(k, 21, { A[k] -= XC(k, t); });
           if ((t + h) < Nt) {
             CSDO_FOR(k, 21, { A[k] -= XC(21 + k, t); });
-            const bool has_rr = (t + 2 * h) < Nt;
-            // (one branch and the 36 reads in flight: as `has_rr ? read : 0.0` per element it was a branch, an LDS round trip and - for
-            //  the zero, a spilled constant - a scratch reload in front of every one of the 36 stores)
-            if (has_rr) {
-              CSDO_FOR(k, 36, { FR(k, t) = XC(42 + k, t); });
-            } else {
-              CSDO_FOR(k, 36, { FR(k, t) = 0.0; });
+            if constexpr (!CSDO_ABSORB_BY_NEIGHBOUR) {
+              const bool has_rr = (t + 2 * h) < Nt;
+              // (one branch and the 36 reads in flight: as `has_rr ? read : 0.0` per element it was a branch, an LDS round trip and - for
+              //  the zero, a spilled constant - a scratch reload in front of every one of the 36 stores)
+              if (has_rr) {
+                CSDO_FOR(k, 36, { FR(k, t) = XC(42 + k, t); });
+              } else {
+                CSDO_FOR(k, 36, { FR(k, t) = 0.0; });
+              }
             }
           }
         } else {
@@ -2166,6 +2186,12 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (t < Nt) {
             V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
             V.ts1 = csdo_keep(tstart[t + 1]);
+            // ... modes 0 and 1: in the two doubles per lane that `carry` does not use during a block (exact as doubles) - as lane
+            // state the pair was spilled and came back from scratch, behind a full wait, at the head of every iteration's rhs assembly
+            if constexpr (MODE < 2 && CSDO_TS_LDS) {
+              SH(carry, 4, t) = (double)V.ts0;
+              SH(carry, 5, t) = (double)V.ts1;
+            }
           }
           unsigned fl = 0;
           if (t < NtE) {
@@ -2244,8 +2270,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           // cluster of vehicles has several planes, and one LDS - or workspace - round trip per plane was the wave's critical path)
           auto add_planes = [&](auto lds_c) __attribute__((always_inline)) {
             constexpr bool L = decltype(lds_c)::value;
-            const int pe = V.ts1;
-            for (int p = V.ts0; p < pe; p += 3) {
+            const int pe = (MODE < 2 && CSDO_TS_LDS) ? (int)SH(carry, 5, t) : V.ts1;
+            for (int p = (MODE < 2 && CSDO_TS_LDS) ? (int)SH(carry, 4, t) : V.ts0; p < pe; p += 3) {
               double v[3][3];
               CSDO_FOR(q, 3, {
                 const int pq = (p + q < pe) ? p + q : p;

@@ -84,6 +84,14 @@ int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) 
     *rows_lds = 1;
   } else {
     *mode = dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) <= LDS_CAP ? 0 : 1;
+    // An obstacle list that does not even fit beside the lean 512-thread layout (mode 1: 52 doubles per timestep) runs in the
+    // 768-thread class, whose modes keep 52 / 30 doubles per timestep in LDS - with lanes to spare for a horizon this short,
+    // slower, but it runs: 5000 obstacles beside 100 timesteps, 3900 beside 200 (mode 1's growth from 46 to 52
+    // doubles had turned worlds away that round 3 accepted; the reference has no such limit at all).
+    if (*mode == 1 && dsqp_lds_bytes(nt, n_obs, n_planes, 1, false) > LDS_CAP) {
+      block = 768;
+      *mode = dsqp_lds_bytes(nt, n_obs, n_planes, 2, false) <= LDS_CAP ? 2 : 3;
+    }
   }
   return block;
 }

@@ -33,6 +33,9 @@
 #if !defined(CSDO_ABSORB_BY_NEIGHBOUR)
 #define CSDO_ABSORB_BY_NEIGHBOUR 1   // mode 0 factorisation: the eliminated node's lane copies the survivor's new coupling out of LDS
 #endif
+#if !defined(CSDO_TAIL_GROUPS)
+#define CSDO_TAIL_GROUPS 1           // the dense tail is inverted with sets of mutually uncoupled pivot blocks ({1,3,5}, {0,4}, {2}): three serial 6x6
+#endif                               // inverses instead of six; another elimination order = other last bits than round 4's results
 #if !defined(CSDO_TS_LDS)
 #define CSDO_TS_LDS 0                // modes 0, 1: a timestep's plane range in LDS (carry's spare doubles) instead of lane state: the rhs assembly loses its
                                      // two scratch reloads and the step gets SLOWER (map100 57.99 -> 58.63 ms): the reloads were hidden, the LDS reads are not

@@ -614,6 +614,91 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
   }
   CSDO_SYNC();
+#if CSDO_TAIL_GROUPS
+  // In-place inversion by BLOCK Gauss-Jordan with SETS of pivot blocks.  The tail system is block tridiagonal (<= 6 nodes of 6), so
+  // its odd nodes are mutually uncoupled, and once they are eliminated so are nodes 0 and 4 of the remaining chain 0 - 2 - 4: three
+  // pivot sets {1, 3, 5}, {0, 4}, {2} (the members that exist) instead of six pivots one after the other - the chain of serial 6x6
+  // inverses, each on one lane with everything else waiting, is three long instead of six, and a set's inverses are formed side by
+  // side.  For a pivot set P with block-diagonal Pinv and everything else R:
+  //   A[P,R] <- Pinv A[P,R];   A[R,R] <- A[R,R] - A[R,P] A[P,R];   A[R,P] <- -A[R,P] Pinv;   A[P,P] <- Pinv
+  // (round 4: one pivot block per step, 35 k cycles per inversion; scalar Gauss-Jordan before that: 77 k).
+  double* const pinv = sh.vec;     // 3 x 36 doubles of scratch: the exchange vectors are dead during the factorisation
+  const int R_nodes = n_tail / 6;
+  for (int grp = 0; grp < 3; ++grp) {
+    // members of the set: node g0 + k * gs for k < ng
+    const int g0 = (grp == 0) ? 1 : ((grp == 1) ? 0 : 2), gsh = (grp == 0) ? 1 : 2, gs = 1 << gsh;   // (stride 2 or 4: shifts, no division)
+    const int ng = (g0 < R_nodes) ? (((R_nodes - 1 - g0) >> gsh) + 1) : 0;
+    if (ng == 0) continue;
+    auto member = [&](const int node) __attribute__((always_inline)) -> int {   // index of the node in the set, or -1
+      const int d = node - g0;
+      return (d >= 0 && (d & (gs - 1)) == 0 && (d >> gsh) < ng) ? (d >> gsh) : -1;
+    };
+    auto node_of = [&](const int rc) __attribute__((always_inline)) -> int {   // rc / 6 for rc < 36
+      return (rc * 43) >> 8;
+    };
+    CSDO_TLANES(t) {   // the set's pivot inverses, one lane each: packed lower triangle -> full 6x6 inverse
+      if (t < ng) {
+        const int p = g0 + t * gs;
+        double Ain[21], Pin[21];
+        CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = SH(tinv, 6 * p + c, 6 * p + r); }); });
+        spd_inverse6(Ain, Pin);
+        CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { pinv[36 * t + r * 6 + c] = Pin[sym(r, c)]; }); });
+      }
+    }
+    CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {   // row blocks: one thread per (member, column outside the set)
+      for (int e = l; e < ng * n_tail; e += nthr) {
+        const int k = (e >= n_tail) + (e >= 2 * n_tail), c = e - k * n_tail;
+        if (member(node_of(c)) < 0) {
+          const int p0 = 6 * (g0 + k * gs);
+          double a[6], nw[6];
+          CSDO_FOR(j, 6, { a[j] = SH(tinv, c, p0 + j); });
+          CSDO_FOR(i, 6, {
+            double v = 0.0;
+            CSDO_FOR(j, 6, { v = fma(pinv[36 * k + i * 6 + j], a[j], v); });
+            nw[i] = v;
+          });
+          CSDO_FOR(i, 6, { SH(tinv, c, p0 + i) = nw[i]; });
+        }
+      }
+    }
+    CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {   // everything outside the set's rows and columns: minus (its columns) x (the set's new rows), member by member
+      for (int e = l; e < n_tail * n_tail; e += nthr) {
+        const int r = e / n_tail, c = e - r * n_tail;   // (by a float reciprocal instead: 57.49 against 57.07 ms - the allocation, not the division)
+        if (member(node_of(r)) < 0 && member(node_of(c)) < 0) {
+          double v = SH(tinv, c, r);
+          for (int k = 0; k < ng; ++k) {
+            const int p0 = 6 * (g0 + k * gs);
+            CSDO_FOR(j, 6, { v = fma(-SH(tinv, p0 + j, r), SH(tinv, c, p0 + j), v); });
+          }
+          SH(tinv, c, r) = v;
+        }
+      }
+    }
+    CSDO_SYNC();
+    CSDO_STHREADS(l, nthr) {   // column blocks, and the pivot blocks themselves (the blocks between two members are zero and stay zero)
+      for (int e = l; e < ng * n_tail; e += nthr) {
+        const int k = (e >= n_tail) + (e >= 2 * n_tail), r = e - k * n_tail;
+        const int p0 = 6 * (g0 + k * gs);
+        const int mr = member(node_of(r));
+        if (mr < 0) {
+          double a[6], nw[6];
+          CSDO_FOR(j, 6, { a[j] = SH(tinv, p0 + j, r); });
+          CSDO_FOR(i, 6, {
+            double v = 0.0;
+            CSDO_FOR(j, 6, { v = fma(-a[j], pinv[36 * k + j * 6 + i], v); });
+            nw[i] = v;
+          });
+          CSDO_FOR(i, 6, { SH(tinv, p0 + i, r) = nw[i]; });
+        } else if (mr == k) {
+          CSDO_FOR(i, 6, { SH(tinv, p0 + i, r) = pinv[36 * k + (r - p0) * 6 + i]; });
+        }
+      }
+    }
+    CSDO_SYNC();
+  }
+#else
   // In-place inversion by BLOCK Gauss-Jordan, one 6x6 pivot block per tail node (the pivot blocks of an SPD matrix are SPD:
   // no pivoting).  Scalar Gauss-Jordan was 36 pivots x 2 barriers of mostly latency (77 k cycles per factorisation); this is
   // <= 6 block pivots x 3 barriers.  For pivot block P (rows / columns 6p .. 6p+5) and everything else R:
@@ -684,6 +769,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       CSDO_SYNC();
     }
   }
+#endif
   if constexpr (MODE == 3) {   // (node 0 is never eliminated: its lane's blocks are loaded with the others and never used)
     CSDO_TLANES(t) {
       if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });

@@ -191,7 +191,7 @@ int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]);
  * workgroups per CU for Nt <= 128 when the working set fits 80 KB, 512 up to Nt = 256, 768 up to 384, 1024 beyond) and LDS residency by
  * working set: 0 = exchange vectors, bounds and the third of the factor that is not in registers in LDS (per agent also
  * the inter-vehicle rows' duals / slacks, where they fit); 1 = that part of the factor read from the workspace instead
- * (512-thread class only); 2 = the 768-thread class with F_r in LDS (horizons to about 296, and only if every 768-thread
+ * (512-thread class only; an agent whose obstacle list does not fit beside that layout either runs in the 768-thread class); 2 = the 768-thread class with F_r in LDS (horizons to about 296, and only if every 768-thread
  * agent of the batch fits it); 3 = the 768- and 1024-thread classes: exchange vectors only.  Every group is a set of persistent
  * workgroups that take its agents off a queue ordered heaviest first, and the groups run concurrently.  `lds_bytes` may
  * be the full 80 / 160 KB of the class: what the agents do not need caches the planes' read-only coefficients.

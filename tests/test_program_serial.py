@@ -137,7 +137,7 @@ def test_corridor_boxes_bit_exact_in_dense_obstacle_fields(oracle, emu, veh_parm
 
 # the agents of the stand-in map100 world (workloads.map100_world(0, front="stand-in")) whose full chain ends between 1e-4 and 1e-3 of
 # the oracle's; tests/test_gpu_parity.py::test_gpu_full_map100_agents50 checks the HIP build against the same list (it returns these bits)
-STAND_IN_MAP100_LOOSE = (6, 13, 16)
+STAND_IN_MAP100_LOOSE = (13, 16)
 
 
 def test_stand_in_world_chain_sensitive_agents(oracle, emu, world_map100):
@@ -147,6 +147,7 @@ def test_stand_in_world_chain_sensitive_agents(oracle, emu, world_map100):
     c = parity.compare(ref, got)
     assert c["counts_equal"] and not [b for b in c["bad"] if b[1] > parity.LOOSE_TOL], c["bad"]
     assert tuple(sorted(b[0] for b in c["bad"])) == STAND_IN_MAP100_LOOSE, c["bad"]
+    assert c["n_flipped"] == 1 and c["d_cor"][6] > 0.05 and c["d_sol"][6] <= parity.CORRIDOR_FLIP_TOL      # agent 6: a flipped growth step, 1.6e-3
     # the reference algorithm is itself rounding-sensitive on the worst of them: the oracle built with fused multiply-adds
     fma = oracle.solve_batch_fma([world], 8)[0]
     assert {b[0] for b in parity.compare(ref, fma)["bad"]} & set(STAND_IN_MAP100_LOOSE)

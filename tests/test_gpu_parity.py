@@ -386,7 +386,7 @@ def test_gpu_obstacle_heavy_short_horizon_runs_in_the_wide_class(gpu_handle, ora
     assert np.abs(got.solutions - ref.solutions).max() <= 1e-5
     usual = gpu_handle.solve(plain)
     assert np.array_equal(got.admm_iters, usual.admm_iters) and np.abs(got.solutions - usual.solutions).max() <= 1e-9
-    assert np.array_equal(got.corridors, usual.corridors)
+    assert np.abs(got.corridors - usual.corridors).max() <= 1e-8      # (the boxes returned are grown at the QP's solution: they follow it)
 
 
 def test_gpu_mixed_batch_launch_groups(gpu_handle, veh_parm):

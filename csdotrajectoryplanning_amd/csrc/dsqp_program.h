@@ -36,6 +36,9 @@
 #if !defined(CSDO_TAIL_GROUPS)
 #define CSDO_TAIL_GROUPS 1           // the dense tail is inverted with sets of mutually uncoupled pivot blocks ({1,3,5}, {0,4}, {2}): three serial 6x6
 #endif                               // inverses instead of six; another elimination order = other last bits than round 4's results
+#if !defined(CSDO_RUIZ_PARK)
+#define CSDO_RUIZ_PARK 1             // nine of the row lane's coefficients wait in LDS between the equilibration's passes
+#endif
 #if !defined(CSDO_TS_LDS)
 #define CSDO_TS_LDS 0                // modes 0, 1: a timestep's plane range in LDS (carry's spare doubles) instead of lane state: the rhs assembly loses its
                                      // two scratch reloads and the step gets SLOWER (map100 57.99 -> 58.63 ms): the reloads were hidden, the LDS reads are not
@@ -278,6 +281,12 @@ CSDO_FN constexpr int row_col(int i, int s) {
                               {2, -1, -1}, {0, 2, -1}, {1, 2, -1}, {0, 2, -1}, {1, 2, -1}, {0, -1, -1},
                               {1, -1, -1}, {4, -1, -1}, {5, -1, -1}, {3, -1, -1}};
   return T[i][s];
+}
+// Ruiz equilibration: the coefficients (row, slot) that wait in LDS between the passes (dsqp_program_impl.h, CSDO_RUIZ_PARK), and where
+CSDO_FN constexpr int ruiz_park_slot(int i, int s) {
+  if (s == 0 && i >= 11 && i <= 15) return i - 11;       // trust x, y; |v|, |w|; |steer|: their single coefficient
+  if (s == 1 && i >= 7 && i <= 10) return 5 + (i - 7);   // corridor rows: the yaw coefficient
+  return -1;
 }
 // kin row i (0..3) touches column i of timestep t+1
 constexpr unsigned ROWS_KIN = 0x000Fu, ROWS_CFG = 0x0070u, ROWS_CTRL = 0x6000u;

@@ -985,6 +985,22 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // ============================================================== Ruiz equilibration (scaling.c scale_data)
     CSDO_MARK("ruiz");
     double cscale = 1.0;
+    // Nine of the row lane's 38 coefficients wait in LDS between the passes (fields 36..44 of the idle block arrays; CSDO_RUIZ_PARK,
+    // modes with that many fields): the single coefficients of the trust, control and steer rows and the corridor rows' yaw
+    // coefficients.  The compiler had made the same choice of its own - nine doubles of the lane in scratch across the pass loop,
+    // 21 reloads and 9 stores per pass, most of them waited for one by one -; parked by the program they are one batch of LDS reads
+    // at the head of a pass and one of writes at its end.  Same operations on the same operands.
+    constexpr bool park = (CSDO_RUIZ_PARK != 0) && (MODE != 3);
+    CSDO_LANES(t) {
+      LaneState& S = CSDO_LS(t);
+      if constexpr (park) {
+        CSDO_FOR(i, NROW, {
+          CSDO_FOR(s_, 3, {
+            if constexpr (ruiz_park_slot(i, s_) >= 0) SU(36 + ruiz_park_slot(i, s_), t) = S.c[i][s_];
+          });
+        });
+      }
+    }
     for (int pass = 0; pass < P.scaling_passes; ++pass) {
       CSDO_SUB_RESET();
       CSDO_LANES(t) {  // hand |cn| and |Pvn| to t+1
@@ -1043,6 +1059,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         double cn_[6] = {0, 0, 0, 0, 0, 0};  // column norms of [P; A]
         double* Dt = S.b;                    // scratch: per-column factor of this pass
         double* Et = S.z;                    // scratch: per-row factor of this pass
+        double pk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // the parked coefficients, for the length of this block
+        if constexpr (park) CSDO_FOR(k, 9, { pk[k] = SU(36 + k, t); });
+#define RC(i, s_) (*((park && ruiz_park_slot(i, s_) >= 0) ? &pk[ruiz_park_slot(i, s_) >= 0 ? ruiz_park_slot(i, s_) : 0] : &S.c[i][s_]))
         if (t > 0) {
           CSDO_FOR(k, 4, { cn_[k] = SU(k, t - 1); });
           cn_[4] = SU(4, t - 1);
@@ -1064,7 +1083,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             double rn = 0.0;
             CSDO_FOR(s, 3, {
               if constexpr (row_col(i, s) >= 0) {
-                const double a = fabs(S.c[i][s]);
+                const double a = fabs(RC(i, s));
                 rn = nmax(rn, a);
                 cn_[row_col(i, s)] = nmax(cn_[row_col(i, s)], a);
               }
@@ -1077,7 +1096,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             constexpr int i = 4 * grp + q;
             if constexpr (i < 4) Et[i] = e4[q];
             CSDO_FOR(s, 3, {
-              if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * e4[q];
+              if constexpr (row_col(i, s) >= 0) RC(i, s) = RC(i, s) * e4[q];
             });
             SU(14 + i, t) = csdo_one_if(pass == 0, eacc[q]) * e4[q];
           });
@@ -1099,9 +1118,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         // factors and the lane's six column factors stay live across it
         CSDO_FOR(i, NROW, {
           CSDO_FOR(s, 3, {
-            if constexpr (row_col(i, s) >= 0) S.c[i][s] = S.c[i][s] * Dt[row_col(i, s)];
+            if constexpr (row_col(i, s) >= 0) RC(i, s) = RC(i, s) * Dt[row_col(i, s)];
           });
         });
+        if constexpr (park) CSDO_FOR(k, 9, { SU(36 + k, t) = pk[k]; });
+#undef RC
         S.Pvv = (S.Pvv * Dt[4]) * Dt[4];
         S.Pww = (S.Pww * Dt[5]) * Dt[5];
         {
@@ -1163,6 +1184,16 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       }
     }
     const double cinv = uniform_f64(1.0 / cscale);
+    CSDO_LANES(t) {   // the parked coefficients come back into the lane's registers for the rest of the QP
+      LaneState& S = CSDO_LS(t);
+      if constexpr (park) {
+        CSDO_FOR(i, NROW, {
+          CSDO_FOR(s_, 3, {
+            if constexpr (ruiz_park_slot(i, s_) >= 0) S.c[i][s_] = SU(36 + ruiz_park_slot(i, s_), t);
+          });
+        });
+      }
+    }
 
   CSDO_PHASE(4);
     // ============================================================== scaled bounds, row classes, warm start

@@ -329,6 +329,7 @@ static int for_each_kid(MultiState& M, F&& f) {
 
 static int multi_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
   MultiState& M = *h->multi;
+  if (h->run_pending) return CSDO_EINVAL;
   for (csdo_handle kid : M.kids)
     if (kid->run_pending) return CSDO_EINVAL;
   h->uploaded = false;

@@ -399,7 +399,7 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 #define CSDO_SINV_LDS 1   // 1: the pivot inverse of a node (21 doubles, read once per iteration in the w pass) sits in LDS; 0: in the workspace
 #endif
 #if !defined(CSDO_ER_REG)
-#define CSDO_ER_REG 30   // pair-split solve (round 4, map100 set, ms per step): 12: 73.4, 18: 71.5, 24: 66.4, 30: 65.8, 36: 71.9 (32 and 34 already put scratch reloads into the levels); one-lane form of round 3: 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
+#define CSDO_ER_REG 34   // round 5 (after the spills of the cold phases went: no reload in the levels at 32, 34, 36 any more), map100 / synth1024 ms per step: 30: 56.90 / 38.14, 32: 56.70 / 37.95, 34: 55.99 / 37.29, 36: 56.39 / 37.59; pair-split solve of round 4: 12: 73.4, 18: 71.5, 24: 66.4, 30: 65.8, 36: 71.9 (32 and 34 put scratch reloads into the levels then); one-lane form of round 3: 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
 #endif
 constexpr int ER_REG = CSDO_ER_REG, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
 // The 768-thread class (residency mode 2, 168 registers per lane): NOTHING of the factor stays in registers across an iteration -

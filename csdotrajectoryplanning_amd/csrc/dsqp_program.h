@@ -401,7 +401,12 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 #if !defined(CSDO_ER_REG)
 #define CSDO_ER_REG 34   // round 5 (after the spills of the cold phases went: no reload in the levels at 32, 34, 36 any more), map100 / synth1024 ms per step: 30: 56.90 / 38.14, 32: 56.70 / 37.95, 34: 55.99 / 37.29, 36: 56.39 / 37.59; pair-split solve of round 4: 12: 73.4, 18: 71.5, 24: 66.4, 30: 65.8, 36: 71.9 (32 and 34 put scratch reloads into the levels then); one-lane form of round 3: 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
 #endif
+#if !defined(CSDO_ER_REG1)
+#define CSDO_ER_REG1 30   // the same for residency mode 1 (its solve still has scratch reloads: with 34 the mode-1 agents of the room set went from 27 to 32 us per iteration)
+#endif
 constexpr int ER_REG = CSDO_ER_REG, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
+constexpr int ER_REG1 = CSDO_ER_REG1, FX_ER1 = 36 - ER_REG1;
+static_assert(ER_REG1 <= ER_REG, "SolvRegs::er is sized for mode 0");
 // The 768-thread class (residency mode 2, 168 registers per lane): NOTHING of the factor stays in registers across an iteration -
 // whatever part was declared lane state there, the allocator spilled and reloaded level by level.  The lane's level-1 block is
 // fetched from the workspace in one batch in front of each of its two uses, the block of its other level sits in LDS, all 36
@@ -471,7 +476,7 @@ constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_car
               // the block's per-timestep arrays (vec .. fx) double as the factorisation's exchange columns, 78 fields x stride
               LD_block = (24 + LD_lohi + LD_fx) > 78 ? (24 + LD_lohi + LD_fx) : 78,
               LD_fx2 = 34, LD_block2 = 18 + LD_fx2,   // mode 2: vec, pr (= rhs), carry (whose two spare doubles per lane hold the block's last two entries) + fx
-              LD_fx1 = 2 * (((FX_ER + 1) / 2) | 1), LD_block1 = 24 + LD_lohi + LD_fx1,   // mode 1: mode 0 without the pivot inverse (and the rows' state)
+              LD_fx1 = 2 * (((FX_ER1 + 1) / 2) | 1), LD_block1 = 24 + LD_lohi + LD_fx1,   // mode 1: mode 0 without the pivot inverse (and the rows' state)
               LD_stash = 38, LD_tinv = 38, LD_prow = 10;
 static_assert(LD_block2 >= LD_stash, "the factorisation parks a 6x6 product and the packed pivot inverse per lane in the block's arrays");
 

@@ -1321,7 +1321,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // Barriers per solve: 3 (levels + gather | tail product beside the w pass | backward) instead of 2 log2(Nt / 6) + 2.
     // Measured: fixed-work iteration 10.45 -> 9.3 us on one instance alone, 2.5 % under a full batch.
     constexpr unsigned XF_ABS = 1u, XF_ABSR = 1u << 6, XF_WR = 1u << 12, XF_OWN = 1u << 18, XF_NR = 1u << 24;
-    constexpr int XER = (MODE == 2) ? ER_REG2 : ER_REG, XFX = 36 - XER;   // the second block: entries in registers / elsewhere
+    constexpr int XER = (MODE == 2) ? ER_REG2 : ((MODE == 1) ? ER_REG1 : ER_REG), XFX = 36 - XER;   // the second block: entries in registers / elsewhere
 #define A2_LDS(k, tt) (*((MODE == 2 && (k) >= LD_fx2) ? &sh.carry[(tt) * LD_carry + 4 + ((k) >= LD_fx2 ? (k) - LD_fx2 : 0)] \
                                                    : &sh.fx[(tt) * (MODE == 2 ? LD_fx2 : (MODE == 1 ? LD_fx1 : LD_fx)) + (k)]))   /* the block's entries beyond XER */
     auto solve_pair = [&](auto before_last_barrier) __attribute__((always_inline)) {   // (generic: only instantiated for the modes that call it)

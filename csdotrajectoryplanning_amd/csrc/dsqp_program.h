@@ -39,6 +39,21 @@
 #if !defined(CSDO_RUIZ_PARK)
 #define CSDO_RUIZ_PARK 1             // nine of the row lane's coefficients wait in LDS between the equilibration's passes
 #endif
+#if !defined(CSDO_ONCE_LOOPS)
+#define CSDO_ONCE_LOOPS 2            // one-trip loops around the two level-1 steps of the solve (round 4: outside any loop of the iteration the level-1 block was what the allocator
+                                     // spilled - still true: 18 reloads per solve without them); 2: as do-while - as `for` loops they cost 42 register copies per iteration (the step's
+                                     // results merged with "what was there before" on a zero-trip path that does not exist): map100 55.91 -> 55.35 ms, synth1024 37.42 -> 37.05
+#endif
+#if CSDO_ONCE_LOOPS == 1
+#define CSDO_ONCE_LOOP for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
+#define CSDO_ONCE_END
+#elif CSDO_ONCE_LOOPS == 2   /* the same as a do-while: no zero-trip path, so what the step defines needs no merge with what was there before */
+#define CSDO_ONCE_LOOP { int once_ = 0; do
+#define CSDO_ONCE_END while (++once_ < csdo_opaque_s(1)); }
+#else
+#define CSDO_ONCE_LOOP
+#define CSDO_ONCE_END
+#endif
 #if !defined(CSDO_TS_LDS)
 #define CSDO_TS_LDS 0                // modes 0, 1: a timestep's plane range in LDS (carry's spare doubles) instead of lane state: the rhs assembly loses its
                                      // two scratch reloads and the step gets SLOWER (map100 57.99 -> 58.63 ms): the reloads were hidden, the LDS reads are not

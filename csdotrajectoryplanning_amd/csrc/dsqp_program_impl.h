@@ -1339,7 +1339,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #endif
         // (the one-trip loops around the two level-1 steps: the register allocator weighs a value by the loop depth of its uses,
         //  and outside any loop of the iteration the level-1 block would be what it spills)
-        for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
+        CSDO_ONCE_LOOP
         CSDO_XLANES(t) {
           SolvRegs& V = CSDO_SS(t);
           // (768-thread class, 168 registers per lane: the level-1 block is not kept across the iteration - as lane state it was
@@ -1368,6 +1368,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (V.fl & XF_ABS) CSDO_FOR(k, 6, { V.b[k] -= left[k]; });
           if (V.fl & XF_ABSR) CSDO_FOR(k, 6, { V.b[k] -= V.o[k]; });
         }
+        CSDO_ONCE_END
         CSDO_XT(1);   // forward level 1
         int lev = 1;
         for (int h = 2; h < h_tail; h <<= 1, ++lev) {
@@ -1619,7 +1620,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             (void)V;
           }
         }
-        for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
+        CSDO_ONCE_LOOP
         CSDO_XLANES(t) {   // level 1: x of the odd nodes, summed and stored by the even lane of the pair
           SolvRegs& V = CSDO_SS(t);
           if constexpr (MODE == 2) CSDO_FOR(k, 36, { V.el[k] = FE(k, t < NtE ? t : NtE - 1); });
@@ -1637,6 +1638,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           CSDO_FOR(k, 6, { ub[k] = CSDO_XGET(CSDO_DPP_PAIR_ODD, o, k); });
           if (V.fl & XF_OWN) CSDO_FOR(k, 6, { SH(vec, k, t + 1) = V.o[k] + ub[k]; });
         }
+        CSDO_ONCE_END
       }
       CSDO_XT(7);   // backward sweep
       CSDO_PHASE(14);

@@ -44,7 +44,10 @@
                                      // spilled - still true: 18 reloads per solve without them); 2: as do-while - as `for` loops they cost 42 register copies per iteration (the step's
                                      // results merged with "what was there before" on a zero-trip path that does not exist): map100 55.91 -> 55.35 ms, synth1024 37.42 -> 37.05
 #endif
-#if CSDO_ONCE_LOOPS == 1
+#if !defined(CSDO_LANE_MODE_DEVICE)   /* (the lane-serial build has no register allocation to steer: a step's lanes-blocks are several statements there) */
+#define CSDO_ONCE_LOOP
+#define CSDO_ONCE_END
+#elif CSDO_ONCE_LOOPS == 1
 #define CSDO_ONCE_LOOP for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
 #define CSDO_ONCE_END
 #elif CSDO_ONCE_LOOPS == 2   /* the same as a do-while: no zero-trip path, so what the step defines needs no merge with what was there before */

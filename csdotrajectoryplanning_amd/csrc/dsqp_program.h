@@ -844,6 +844,180 @@ struct BoxCache {
   unsigned* base;
   int stride, cap;
 };
+#if !defined(CSDO_GROW_PACKED)
+#define CSDO_GROW_PACKED 1   // 1: the stop events decoded from the packed word (below); 0: round 3's side-by-side loops
+#endif
+#if CSDO_GROW_PACKED
+// first_step with the side known at compile time (no selects on d; the four of an obstacle are straight-line code)
+template <int D>
+CSDO_FN int first_step_of(const double xc, const double yc, const double ox, const double oy, const double infl) {
+  constexpr bool vertical = (D & 1) == 0, up = (D == 0 || D == 3);
+  const double c0 = vertical ? yc : xc, o = vertical ? oy : ox;
+  const double g = (up ? ((o - infl) - c0) : (c0 - (o + infl))) * 10.0;
+  if (!(g > -1.0)) return 0;
+  if (!(g < (double)GROW_NEVER)) return GROW_NEVER;
+  const double fl = floor(g);
+  const double frac = g - fl;
+  if (frac < 1e-7 || frac > 1.0 - 1e-7) {
+#if defined(CSDO_GROW_STATS)
+    csdo_grow_stats[1]++;
+#endif
+    const double step = up ? 0.1 : -0.1;
+    double c = c0;
+    int n = 0;
+    while (n < GROW_NEVER && !(up ? (o < (c + infl)) : ((c - infl) < o))) {
+      c += step;
+      ++n;
+    }
+    return n;
+  }
+  return (g < 0.0) ? 0 : (int)fl + 1;
+}
+CSDO_FN unsigned obstacle_steps(const double xc, const double yc, const double ox, const double oy, const double infl) {
+  return (unsigned)first_step_of<0>(xc, yc, ox, oy, infl) | ((unsigned)first_step_of<1>(xc, yc, ox, oy, infl) << 8) |
+         ((unsigned)first_step_of<2>(xc, yc, ox, oy, infl) << 16) | ((unsigned)first_step_of<3>(xc, yc, ox, oy, infl) << 24);
+}
+// The culled obstacles in mask order (the order of their cache slots)
+struct ObsWalk {
+  unsigned long long m0, m1, m2, m3;
+  int k_tail;
+};
+CSDO_FN bool next_obstacle(ObsWalk& w, const int n_obs, int& k) {
+  if (w.m0) {
+    k = ctz64(w.m0);
+    w.m0 &= w.m0 - 1;
+  } else if (w.m1) {
+    k = 64 + ctz64(w.m1);
+    w.m1 &= w.m1 - 1;
+  } else if (w.m2) {
+    k = 128 + ctz64(w.m2);
+    w.m2 &= w.m2 - 1;
+  } else if (w.m3) {
+    k = 192 + ctz64(w.m3);
+    w.m3 &= w.m3 - 1;
+  } else if (w.k_tail < n_obs) {
+    k = w.k_tail++;
+  } else {
+    return false;
+  }
+  return true;
+}
+// n sequential additions of `step` (the reference's own sums), eight to a trip: a trip per addition was a branch per addition,
+// and the wave runs as many trips as its longest lane
+CSDO_FN double add_steps(double c, const double step, int n) {
+  for (; n >= 8; n -= 8) {
+    c += step; c += step; c += step; c += step;
+    c += step; c += step; c += step; c += step;
+  }
+  for (; n > 0; --n) c += step;
+  return c;
+}
+CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
+                      BoxD& res, const BoxCache& ec, const ObsMask& M) {
+  const double ds = 0.1;
+#if defined(CSDO_GROW_STATS)
+  csdo_grow_stats[0]++;
+#endif
+  // round in which a side's trial fails for a reason of its own: the map border, or the step after the last allowed one
+  int stop0 = 1, stop1 = 1, stop2 = 1, stop3 = 1;
+  {
+    const double x_hi = dimx - rv, y_hi = dimy - rv;
+    if (!(xc < rv || xc > x_hi || yc < rv || yc > y_hi)) {
+      const int lim = GROW_LIMIT + 1;
+      int v;
+      v = first_step_of<0>(xc, yc, x_hi, y_hi, 0.0); stop0 = v < 1 ? 1 : (v > lim ? lim : v);
+      v = first_step_of<1>(xc, yc, rv, y_hi, 0.0);   stop1 = v < 1 ? 1 : (v > lim ? lim : v);
+      v = first_step_of<2>(xc, yc, x_hi, rv, 0.0);   stop2 = v < 1 ? 1 : (v > lim ? lim : v);
+      v = first_step_of<3>(xc, yc, x_hi, y_hi, 0.0); stop3 = v < 1 ? 1 : (v > lim ? lim : v);
+    }
+  }
+  int st0 = 0, st1 = 0, st2 = 0, st3 = 0;   // accepted steps of the sides that have stopped
+  unsigned moving = 0xFu;
+  bool seed_inside = false;
+  int n_seen = 0;   // culled obstacles (counted by the first pass); the first min(n_seen, cap) have their word in the cache
+#if defined(CSDO_ABL_BOX2X_PASSES)   // diagnostic: the passes twice, same results (what they cost = the difference)
+  for (int rep_ = 0; rep_ < csdo_opaque_s(2); ++rep_) {
+  st0 = st1 = st2 = st3 = 0; moving = 0xFu; seed_inside = false; n_seen = 0;
+#endif
+  for (int pass = 0; pass < 4 && !seed_inside; ++pass) {
+    // earliest trial that fails, key = 4 * round + side
+    int best = 4 * (GROW_LIMIT + 2);
+    if (moving & 1u) best = 4 * stop0 + 0 < best ? 4 * stop0 + 0 : best;
+    if (moving & 2u) best = 4 * stop1 + 1 < best ? 4 * stop1 + 1 : best;
+    if (moving & 4u) best = 4 * stop2 + 2 < best ? 4 * stop2 + 2 : best;
+    if (moving & 8u) best = 4 * stop3 + 3 < best ? 4 * stop3 + 3 : best;
+    // An obstacle's four step counts E (one byte each, <= GROW_NEVER = 120) against the state of the pass, without a loop over
+    // the sides.  The stopped sides must have their inequality true where they stopped (E <= accepted steps, <= 101): with the
+    // bytes 0x80 | st (0x80 | 0x7f for a moving side) minus the bytes of E no byte borrows, and a byte keeps its top bit exactly
+    // when E <= st.  Among the moving sides the obstacle is entered in round mx = max E by the LAST side that attains it:
+    // 4 * mx + last is the maximum of 4 * E + side over the moving sides.
+    const unsigned stp = 0x80808080u | (unsigned)((moving & 1u) ? 0x7f : st0) | ((unsigned)((moving & 2u) ? 0x7f : st1) << 8) |
+                         ((unsigned)((moving & 4u) ? 0x7f : st2) << 16) | ((unsigned)((moving & 8u) ? 0x7f : st3) << 24);
+    const unsigned emask = ((moving & 1u) ? 0xffu : 0u) | ((moving & 2u) ? 0xff00u : 0u) | ((moving & 4u) ? 0xff0000u : 0u) |
+                           ((moving & 8u) ? 0xff000000u : 0u);
+    const unsigned d1 = (moving & 2u) ? 1u : 0u, d2 = (moving & 4u) ? 2u : 0u, d3 = (moving & 8u) ? 3u : 0u;
+    auto consider = [&](const unsigned packed) __attribute__((always_inline)) {
+      const bool live = ((stp - packed) & 0x80808080u) == 0x80808080u;
+      const unsigned pm = packed & emask;
+      const unsigned k0 = (pm & 0xffu) << 2, k1 = (((pm >> 8) & 0xffu) << 2) | d1, k2 = (((pm >> 16) & 0xffu) << 2) | d2,
+                     k3 = ((pm >> 24) << 2) | d3;
+      const unsigned k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+      const int key = (int)(k01 > k23 ? k01 : k23);
+      if (live && key < 4) seed_inside = true;   // every inequality holds at the seed: no trial can succeed
+      if (live && key < best) best = key;
+    };
+    if (pass == 0) {
+      ObsWalk w{M.m[0], M.m[1], M.m[2], M.m[3], OBS_MASK_CAP};
+      int k;
+      while (next_obstacle(w, n_obs, k)) {
+        const unsigned packed = obstacle_steps(xc, yc, obs[k], obs[n_obs + k], obs[2 * n_obs + k]);   // (radius staged as r_obs + rv)
+        if (n_seen < ec.cap) ec.base[(size_t)n_seen * (size_t)ec.stride] = packed;
+        ++n_seen;
+        consider(packed);
+      }
+    } else {
+      const int n_cached = n_seen < ec.cap ? n_seen : ec.cap;
+      for (int j = 0; j < n_cached; ++j) consider(ec.base[(size_t)j * (size_t)ec.stride]);
+      if (n_seen > n_cached) {   // more obstacles in reach than cache slots: the rest is recomputed
+        ObsWalk w{M.m[0], M.m[1], M.m[2], M.m[3], OBS_MASK_CAP};
+        int k, j = 0;
+        while (next_obstacle(w, n_obs, k)) {
+          if (j++ < n_cached) continue;
+          consider(obstacle_steps(xc, yc, obs[k], obs[n_obs + k], obs[2 * n_obs + k]));
+        }
+      }
+    }
+    const int side = best & 3, round = best >> 2;
+    if (side == 0) st0 = round - 1;
+    if (side == 1) st1 = round - 1;
+    if (side == 2) st2 = round - 1;
+    if (side == 3) st3 = round - 1;
+    moving &= ~(1u << side);
+  }
+#if defined(CSDO_ABL_BOX2X_PASSES)
+  }
+#endif
+  if (seed_inside) {   // (only ever found in the first pass: later, an obstacle that holds the box would have stopped a side)
+    res = BoxD{xc, yc, xc, yc};
+    return false;
+  }
+  // replay: the coordinates are the same sums as in the reference's walk
+  BoxD box{xc, yc, xc, yc};
+#if defined(CSDO_ABL_BOX2X_REPLAY)
+  for (int rep_ = 0; rep_ < csdo_opaque_s(2); ++rep_) {
+  box = BoxD{xc, yc, xc, yc};
+#endif
+  box.y_max = add_steps(yc, ds, st0 < GROW_LIMIT ? st0 : GROW_LIMIT);
+  box.x_min = add_steps(xc, -ds, st1 < GROW_LIMIT ? st1 : GROW_LIMIT);
+  box.y_min = add_steps(yc, -ds, st2 < GROW_LIMIT ? st2 : GROW_LIMIT);
+  box.x_max = add_steps(xc, ds, st3 < GROW_LIMIT ? st3 : GROW_LIMIT);
+#if defined(CSDO_ABL_BOX2X_REPLAY)
+  }
+#endif
+  res = box;
+  return (st0 + st1 + st2 + st3) > 0;
+}
+#else
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
                       BoxD& res, const BoxCache& ec, const ObsMask& M) {
   const double ds = 0.1;
@@ -871,6 +1045,10 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
   int st0 = 0, st1 = 0, st2 = 0, st3 = 0;   // accepted steps of the sides that have stopped
   unsigned moving = 0xFu;
   bool seed_inside = false;
+#if defined(CSDO_ABL_BOX2X_PASSES)   // diagnostic: the passes twice, same results (what they cost = the difference)
+  for (int rep_ = 0; rep_ < csdo_opaque_s(2); ++rep_) {
+  st0 = st1 = st2 = st3 = 0; moving = 0xFu; seed_inside = false;
+#endif
   for (int pass = 0; pass < 4 && !seed_inside; ++pass) {
     // earliest trial that fails, key = 4 * round + side
     int best = 4 * (GROW_LIMIT + 2);
@@ -941,6 +1119,9 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
     if (side == 3) st3 = round - 1;
     moving &= ~(1u << side);
   }
+#if defined(CSDO_ABL_BOX2X_PASSES)
+  }
+#endif
   if (seed_inside) {   // (only ever found in the first pass: later, an obstacle that holds the box would have stopped a side)
     res = BoxD{xc, yc, xc, yc};
     return false;
@@ -949,15 +1130,23 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
   // (a loop per side, as long as that side's step count: one loop over all GROW_LIMIT steps with four tests and selects per step
   //  was 23 k cycles per SQP iteration for 4 x 101 additions)
   BoxD box{xc, yc, xc, yc};
+#if defined(CSDO_ABL_BOX2X_REPLAY)
+  for (int rep_ = 0; rep_ < csdo_opaque_s(2); ++rep_) {
+  box = BoxD{xc, yc, xc, yc};
+#endif
   const int lim0 = st0 < GROW_LIMIT ? st0 : GROW_LIMIT, lim1 = st1 < GROW_LIMIT ? st1 : GROW_LIMIT,
             lim2 = st2 < GROW_LIMIT ? st2 : GROW_LIMIT, lim3 = st3 < GROW_LIMIT ? st3 : GROW_LIMIT;
   for (int n = 0; n < lim0; ++n) box.y_max += ds;
   for (int n = 0; n < lim1; ++n) box.x_min -= ds;
   for (int n = 0; n < lim2; ++n) box.y_min -= ds;
   for (int n = 0; n < lim3; ++n) box.x_max += ds;
+#if defined(CSDO_ABL_BOX2X_REPLAY)
+  }
+#endif
   res = box;
   return (st0 + st1 + st2 + st3) > 0;
 }
+#endif
 
 // generateBox, corridor.cc:124-159.  Returns bit0 = success, bits1-2 = initial status (0 legal, 1 out of map,
 // 2 inside an inflated obstacle).  First colliding obstacle = lowest input index (documented deviation from the
@@ -979,6 +1168,9 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
   }
   int hit = -1;   // isPointCollision, and the obstacles within reach of a box grown from the point, in one walk
   ObsMask M = cull_obstacles(x, y, obs, n_obs, rv, hit);
+#if defined(CSDO_ABL_BOX2X_CULL)
+  for (int rep_ = 1; rep_ < csdo_opaque_s(2); ++rep_) M = cull_obstacles(x, y, obs + csdo_opaque_s(0), n_obs, rv, hit);
+#endif
   // One call site for the growth: from the point itself, or (generateLegalPoint, corridor.cc:84-122) from up to 20 points on
   // a circle around the obstacle the point is inside of, alternating sides, until a grown box is valid against every obstacle.
   bool success = false;
@@ -1067,6 +1259,9 @@ CSDO_FN int box_at(const double x, const double y, const double* obs, const int 
 template <bool CALL>
 CSDO_FN int box_at(const double x, const double y, const double* obs, const int n_obs, const double dimx, const double dimy,
                    const double rv, BoxD& res, const BoxCache& ec) {
+#if defined(CSDO_ABL_BOX2X_ALL)   // diagnostic: every box twice
+  for (int rep_ = 1; rep_ < csdo_opaque_s(2); ++rep_) make_box(x, y, obs + csdo_opaque_s(0), n_obs, dimx, dimy, rv, res, ec);
+#endif
   return make_box(x, y, obs, n_obs, dimx, dimy, rv, res, ec);
 }
 #endif

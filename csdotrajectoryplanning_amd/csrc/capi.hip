@@ -141,14 +141,15 @@ static int build_groups(csdo_handle h) {
   for (int a = 0; a < Na; ++a) {
     AgentDesc& ad = hbm.agents[a];
     const int n_obs = hb.worlds[ad.world].n_obs;
-    int rows = 0;
-    key[a].block = dsqp_agent_class(ad.Nt, n_obs, ad.n_planes, &key[a].mode, &rows);
+    int rows = 0, tail = TAIL_NODES;
+    key[a].block = dsqp_agent_class(ad.Nt, n_obs, ad.n_planes, &key[a].mode, &rows, &tail);
+    ad.tail_nodes = tail;   // (a function of the agent alone: the one item of the class that the results' last bits depend on)
     // testing knob (results never depend on it): 1 keeps the inter-vehicle rows' state in the workspace, 2 also reads the
     // LDS part of the factor from the workspace (512-thread class; the 1024-thread class is always mode 3)
     if (h->min_mode >= 1) rows = 0;
     if (h->min_mode >= 2 && key[a].block == 512) key[a].mode = 1;
     ad.rows_lds = rows;
-    need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode, rows != 0);
+    need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode, rows != 0, tail);
   }
   // One residency mode for the 768-thread class of a batch: with F_r in LDS (mode 2) where every such agent fits, else the
   // lean mode 3 for all of them.  Every (class, mode) pair is a launch group with streams of its own, HIP maps streams onto four
@@ -709,7 +710,8 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
         const int a = h->order[g.first + i];
         const AgentDesc& ad = hb.agents[a];
         int mode = 0, rows = 0;
-        dsqp_agent_class(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, &mode, &rows);
+        int tail_ = 0;
+        dsqp_agent_class(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, &mode, &rows, &tail_);
         if (dsqp_lds_bytes(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, mode, false) > dsqp_lds_capacity()) {
           h->limit_world = ad.world;
           h->limit_agent = a - hb.world_first_agent[ad.world];

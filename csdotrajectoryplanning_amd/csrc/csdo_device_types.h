@@ -17,6 +17,9 @@ struct AgentDesc {
   int32_t world;       // index into WorldDesc
   int32_t n_planes;    // K_a
   int32_t rows_lds;    // 1: the inter-vehicle rows' duals / slacks / rhs shares fit LDS beside the rest (set by the launcher)
+  int32_t tail_nodes;  // capacity of the dense tail of the BCR solve in 6x6 nodes: 6, or 8 / 12 (512-thread class; dsqp_class.h: a
+                       // function of the agent alone, the lane-serial build applies the same rule); 0 = 6
+  int32_t pad_;
   int64_t x0_off;      // element offset of x0[Nt][6] (in doubles)
   int64_t plane_off;   // first plane of this agent
   int64_t tstart_off;  // offset of tstart[Nt+1]

@@ -51,50 +51,9 @@ hipError_t launch_math_probe(int fn, const double* a, const double* b, double* o
   return hipGetLastError();
 }
 
-size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds) {
-  const int st = (nt + 1) & ~1;
-  // exchange vectors vec, pr, rhs, carry (6 each) + bounds of the home rows 22 (the t -> t-1 hand-over aliases them) +
-  // the third of the factor that is not in the solver lane's registers 34 (mode 0); mode 3: vec, pr, rhs, carry, carry2
-  const size_t per_lane = mode == 3 ? 30 : (mode == 2 ? (size_t)LD_block2 : (mode == 1 ? (size_t)LD_block1 : (size_t)LD_block));
-  const size_t n_obs_pad = (3 * (size_t)n_obs + 1) & ~(size_t)1, n_pc_pad = (3 * (size_t)n_planes + 1) & ~(size_t)1;
-  const size_t planes = (mode == 0 && rows_lds) ? n_pc_pad + (size_t)LD_prow * n_planes : 0;   // rhs shares + duals / slacks
-  return (per_lane * st + n_obs_pad + 32 + 2 * TAIL_N + TAIL_N * 38 + planes) * sizeof(double);
-}
-
-constexpr size_t LDS_CAP = 160 * 1024 - 64;   // 160 KB per workgroup minus the kernel's static LDS (queue slot)
-constexpr size_t LDS_CAP_2WG = 80 * 1024 - 64;   // two workgroups of the 256-thread class per CU
 size_t dsqp_lds_capacity() { return LDS_CAP; }
 size_t dsqp_lds_capacity_two_per_cu() { return LDS_CAP_2WG; }
 int dsqp_workgroups_per_cu(int block, size_t lds_bytes) { return (block == 256 && lds_bytes <= LDS_CAP_2WG) ? 2 : 1; }
-
-int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds) {
-  // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024
-  // threads with 128 registers per lane: correct but spills; horizons that long are outside the benchmark sets)
-  // The 256-thread class runs two workgroups per CU, so it only takes agents whose working set fits half the LDS; a
-  // short horizon that does not (Nt > ~105 with 25 obstacles) runs in the 512-thread class with half its lanes idle.
-  // Horizons 257 .. 384 take 768 threads: three waves per SIMD leave 168 registers per lane instead of 128 (measured on the
-  // room set, whose long agents have 257 .. 295 timesteps).
-  int block = nt <= 128 ? 256 : (nt <= 256 ? 512 : (nt <= 384 ? 768 : 1024));
-  if (block == 256 && dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) > LDS_CAP_2WG) block = 512;
-  *rows_lds = 0;
-  if (block >= 768) {   // nothing of the factor in registers: F_r in LDS where that fits (mode 2), else from the workspace
-    *mode = (block == 768 && dsqp_lds_bytes(nt, n_obs, n_planes, 2, false) <= LDS_CAP) ? 2 : 3;
-  } else if (dsqp_lds_bytes(nt, n_obs, n_planes, 0, true) <= (block == 256 ? LDS_CAP_2WG : LDS_CAP)) {   // (256: keep two per CU)
-    *mode = 0;
-    *rows_lds = 1;
-  } else {
-    *mode = dsqp_lds_bytes(nt, n_obs, n_planes, 0, false) <= LDS_CAP ? 0 : 1;
-    // An obstacle list that does not even fit beside the lean 512-thread layout (mode 1: 52 doubles per timestep) runs in the
-    // 768-thread class, whose modes keep 52 / 30 doubles per timestep in LDS - with lanes to spare for a horizon this short,
-    // slower, but it runs: 5000 obstacles beside 100 timesteps, 3900 beside 200 (mode 1's growth from 46 to 52
-    // doubles had turned worlds away that round 3 accepted; the reference has no such limit at all).
-    if (*mode == 1 && dsqp_lds_bytes(nt, n_obs, n_planes, 1, false) > LDS_CAP) {
-      block = 768;
-      *mode = dsqp_lds_bytes(nt, n_obs, n_planes, 2, false) <= LDS_CAP ? 2 : 3;
-    }
-  }
-  return block;
-}
 
 hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream) {
   if (g.count <= 0 || workgroups <= 0) return hipSuccess;

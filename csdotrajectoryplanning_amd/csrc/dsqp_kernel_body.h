@@ -19,7 +19,7 @@ __device__ __forceinline__ T* aligned16(T* p) {
   return (T*)__builtin_assume_aligned(p, 16);
 }
 
-template <int MODE>
+template <int MODE, bool BIGT>
 __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, double* lds, const int lds_doubles) {
   const int ad_Nt = uniform_i32(B.agents[agent].Nt);
   const long long ad_fac_off = uniform_i64(B.agents[agent].fac_off);
@@ -66,8 +66,19 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
   sh.obs = rest;
   sh.bcast = aligned16(sh.obs + n_obs_pad);
   sh.tvec = aligned16(sh.bcast + 32);
-  sh.tinv = aligned16(sh.tvec + 2 * TAIL_N);
-  rest = sh.tinv + TAIL_N * 38;
+  if constexpr (BIGT) {   // the tail's capacity is the agent's (dsqp_class.h; the same sizes as dsqp_lds_bytes)
+    const int tn = uniform_i32(B.agents[agent].tail_nodes);
+    const int cap = tn > TAIL_NODES ? 6 * tn : TAIL_N;
+    sh.tvec_half = tn > TAIL_NODES ? TAIL_N_BIG : TAIL_N;
+    sh.ld_tinv = cap + 2;
+    sh.tinv = aligned16(sh.tvec + 2 * sh.tvec_half);
+    rest = sh.tinv + cap * (cap + 2);
+  } else {
+    sh.tvec_half = TAIL_N;
+    sh.ld_tinv = 38;
+    sh.tinv = aligned16(sh.tvec + 2 * TAIL_N);
+    rest = sh.tinv + TAIL_N * 38;
+  }
   sh.pcg = B.rows_ws + ad_rows_off * ROWS_WS_STRIDE + (size_t)32 * ad_n_planes;
   if constexpr (MODE == 0) {   // only used by agents with AgentDesc::rows_lds (the launch sized the LDS for them)
     const int n_pc_pad = 2 * ((3 * ad_n_planes + 1) >> 1);
@@ -123,11 +134,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
         B.prof[(int64_t)agent * 48 + 46] = ((long long)(xcc & 0xf) << 32) | hw;
       }
 #endif
-      const Shm sh = carve_lds<MODE>(B, agent, lds, lds_doubles);
+      const Shm sh = carve_lds<MODE, (BLOCK == 512)>(B, agent, lds, lds_doubles);
       ProgramOut po;
       RowRegs lr;
       SolvRegs ls_unused;
-      agent_program<ROLE_ROW, MODE>(B, agent, sh, lr, ls_unused, po);
+      agent_program<ROLE_ROW, MODE, (BLOCK == 512)>(B, agent, sh, lr, ls_unused, po);
       if (threadIdx.x == 0) {
         B.sqp_iters[agent] = po.sqp_iters;
         B.admm_iters[agent] = po.admm_iters;
@@ -143,11 +154,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
       __syncthreads();
       if (q_idx >= count) break;
       const int agent = uniform_i32(B.order[first + q_idx]);
-      const Shm sh = carve_lds<MODE>(B, agent, lds, lds_doubles);
+      const Shm sh = carve_lds<MODE, (BLOCK == 512)>(B, agent, lds, lds_doubles);
       ProgramOut po;
       RowRegs lr_unused;
       SolvRegs ls;
-      agent_program<ROLE_SOLVER, MODE>(B, agent, sh, lr_unused, ls, po);
+      agent_program<ROLE_SOLVER, MODE, (BLOCK == 512)>(B, agent, sh, lr_unused, ls, po);
     }
   }
 }

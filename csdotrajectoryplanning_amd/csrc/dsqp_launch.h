@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "csdo_device_types.h"
+#include "dsqp_class.h"
 
 namespace csdo {
 // One launch = one group of agents that share a kernel instantiation: workgroup size by horizon and LDS residency
@@ -17,12 +18,9 @@ struct LaunchGroup {
   int* queue = nullptr;       // device counter of the group's agent queue (persistent workgroups)
   int primary = 0, elastic = 0;   // workgroups of the first launch (the group's share of the CUs) and of the second one
 };
-size_t dsqp_lds_bytes(int nt, int n_obs, int n_planes, int mode, bool rows_lds);   // LDS working set of one agent
 int dsqp_workgroups_per_cu(int block, size_t lds_bytes);            // persistent workgroups of a launch group one CU holds
 size_t dsqp_lds_capacity_two_per_cu();                             // ... of the class that runs two workgroups per CU
 size_t dsqp_lds_capacity();                                        // dynamic LDS one workgroup may ask for
-// kernel class of one agent: returns the workgroup size, sets the residency mode and whether the rows' state fits LDS
-int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds);
 // Launches `workgroups` persistent workgroups that drain the group's queue (g.queue must have been zeroed on a stream
 // this launch is ordered after); several launches may share one queue.
 hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream);

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "csdo_device_types.h"
+#include "dsqp_layout.h"
 
 // experiment switches of round 5 (each measured with old and new library interleaved on one box, scripts/gpu_ab.sh)
 #if !defined(CSDO_ABSORB_BY_NEIGHBOUR)
@@ -292,7 +293,7 @@ constexpr int NROW = 16;
 constexpr int NCOLS = 6;
 // BCR stops when at most TAIL_NODES nodes remain; the remaining block-tridiagonal system (<= 36 unknowns) is solved
 // with its explicit dense inverse by 6*R lanes in one phase instead of log2(R)+1 forward and backward level phases.
-constexpr int TAIL_NODES = 6, TAIL_N = 6 * TAIL_NODES;
+// (TAIL_NODES, TAIL_N, TAIL_NODES_BIG, TAIL_N_BIG: dsqp_layout.h)
 
 CSDO_FN constexpr int row_col(int i, int s) {
   constexpr int T[NROW][3] = {{0, 2, 4}, {1, 2, 4}, {2, 3, 4}, {3, 5, -1}, {0, -1, -1}, {1, -1, -1},
@@ -413,17 +414,6 @@ CSDO_FN constexpr int sym(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : 
 // the 512-thread kernel has per lane) the allocator spills a third of it to scratch, and a scratch reload inside a BCR
 // level costs more than the LDS read it replaced (measured: 160 ms against 140 ms per step on the map100 set); 60 doubles
 // leave the hot loop spill-free.  The other 33 sit in LDS (Shm::fx): read by one lane, once per sweep.
-#if !defined(CSDO_SINV_LDS)
-#define CSDO_SINV_LDS 1   // 1: the pivot inverse of a node (21 doubles, read once per iteration in the w pass) sits in LDS; 0: in the workspace
-#endif
-#if !defined(CSDO_ER_REG)
-#define CSDO_ER_REG 34   // round 5 (after the spills of the cold phases went: no reload in the levels at 32, 34, 36 any more), map100 / synth1024 ms per step: 30: 56.90 / 38.14, 32: 56.70 / 37.95, 34: 55.99 / 37.29, 36: 56.39 / 37.59; pair-split solve of round 4: 12: 73.4, 18: 71.5, 24: 66.4, 30: 65.8, 36: 71.9 (32 and 34 put scratch reloads into the levels then); one-lane form of round 3: 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
-#endif
-#if !defined(CSDO_ER_REG1)
-#define CSDO_ER_REG1 30   // the same for residency mode 1 (its solve still has scratch reloads: with 34 the mode-1 agents of the room set went from 27 to 32 us per iteration)
-#endif
-constexpr int ER_REG = CSDO_ER_REG, FX_ER = 36 - ER_REG;   // fx[lane] = F_r[ER_REG..36) then the packed pivot inverse
-constexpr int ER_REG1 = CSDO_ER_REG1, FX_ER1 = 36 - ER_REG1;
 static_assert(ER_REG1 <= ER_REG, "SolvRegs::er is sized for mode 0");
 // The 768-thread class (residency mode 2, 168 registers per lane): NOTHING of the factor stays in registers across an iteration -
 // whatever part was declared lane state there, the allocator spilled and reloaded level by level.  The lane's level-1 block is
@@ -431,11 +421,6 @@ static_assert(ER_REG1 <= ER_REG, "SolvRegs::er is sized for mode 0");
 // entries (Shm::fx, LD_fx2 = 34 doubles per lane - 2 x odd: conflict-free 128-bit reads - and the two doubles per lane that
 // Shm::carry does not use); to make room the rows' rhs shares use the right partials' array (see Shm::rhs).
 // 18 + 34 = 52 doubles per timestep: horizons to 350 beside 238 obstacles; longer ones run mode 3.
-#if !defined(CSDO_ER_REG2)
-#define CSDO_ER_REG2 0
-#endif
-constexpr int ER_REG2 = CSDO_ER_REG2, FX_ER2 = 36 - ER_REG2;
-
 struct RowRegs {            // row lane of timestep t: the 16 home constraint rows and the 6 variables
   double c[NROW][3];        // scaled coefficients on own columns
   double cn[4];             // scaled coefficient of kin rows on column i of t+1
@@ -490,12 +475,6 @@ enum WsSlot {
 // lane-major leading dimensions (doubles per lane) of the LDS arrays.  All are 2 * odd: 16-byte aligned lanes, and the
 // ds_read_b128 / ds_write_b128 of 16 consecutive lanes (also of lanes a power of two apart) fall into 16 different
 // 4-bank groups - conflict free.  (12 doubles, the former reduction stride, is 2-way conflicting.)
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + (CSDO_SINV_LDS ? 21 : 0) + 1) / 2) | 1),
-              // the block's per-timestep arrays (vec .. fx) double as the factorisation's exchange columns, 78 fields x stride
-              LD_block = (24 + LD_lohi + LD_fx) > 78 ? (24 + LD_lohi + LD_fx) : 78,
-              LD_fx2 = 34, LD_block2 = 18 + LD_fx2,   // mode 2: vec, pr (= rhs), carry (whose two spare doubles per lane hold the block's last two entries) + fx
-              LD_fx1 = 2 * (((FX_ER1 + 1) / 2) | 1), LD_block1 = 24 + LD_lohi + LD_fx1,   // mode 1: mode 0 without the pivot inverse (and the rows' state)
-              LD_stash = 38, LD_tinv = 38, LD_prow = 10;
 static_assert(LD_block2 >= LD_stash, "the factorisation parks a 6x6 product and the packed pivot inverse per lane in the block's arrays");
 
 // Shared (LDS) arrays, lane-major: element k of lane t at arr[t * LD + k]
@@ -520,8 +499,10 @@ struct Shm {
   double* facX;     // [100][stride] factor-time exchange and the nodes' diagonal blocks (global, coalesced)
   double* cold;     // [C_TOTAL][stride] per-agent workspace (global)
   double* bcast;    // [32] block-wide results
-  double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane
-  double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row
+  double* tinv;     // [36][38] dense inverse of the BCR tail system, one row per tail lane (BIGT: [6 tn][6 tn + 2])
+  double* tvec;     // [2][36] tail rhs gather / Gauss-Jordan pivot row (BIGT: [2][72])
+  int ld_tinv;      // BIGT kernels: row stride of tinv, 6 * tail_nodes + 2
+  int tvec_half;    // BIGT kernels: offset of tvec's second half (36, or 72 for a tail of more than six nodes)
   double* pc;       // [K][3]  per-plane share of A'(rho z - y) for the next rhs, LDS copy (agents whose planes fit: rows_lds)
   double* pcg;      // [K][3]  the same in the workspace (all other agents)
   double* prow;     // [K][10] rows_lds: duals, slacks (y[4], z[4]) and timestep of a plane's four inter-vehicle rows during

@@ -162,7 +162,7 @@ struct FactorProf {};
 #define CSDO_FPHASE(k) ((void)0)
 #endif
 #endif
-template <int ROLE, int MODE>
+template <int ROLE, int MODE, bool BIGT>
 CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t rcap_in, const int32_t* tstart_in,
                               const int Nt_in, const int h_tail_in, const int n_tail_in, const double sigma_in,
                               const double rho_in, const FactorProf fprof) {
@@ -172,6 +172,10 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   const int32_t* tstart = tstart_in;
   const int Nt = Nt_in, Nm = Nt - 1, h_tail = h_tail_in, n_tail = n_tail_in;
   const double sigma = sigma_in, rho_now = rho_in;
+  // the tail's inverse: row stride and capacity (a constant but for the kernels that read the tail's size at run time, BIGT)
+  const int ldt = BIGT ? sh.ld_tinv : (int)LD_tinv;
+  const int tcap = BIGT ? (ldt - 2) : (int)TAIL_N;
+#define TINV(c, r) sh.tinv[(r) * ldt + (c)]
   CSDO_SYNC();  // the row lanes' workspace writes (set-up stage / save) must be visible to the solver lanes
   CSDO_SLANES(t) {
     const unsigned act = (unsigned)WS(W_ACT, t), eqm = (unsigned)WS(W_EQ, t), lom = (unsigned)WS(W_LOOSE, t);
@@ -600,8 +604,8 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   CSDO_STHREADS(l, nthr) {
     // (element by element: three elements of a thread at a time with their loads in flight together was measured slower, 61.6
     //  against 61.3 ms - the extra address arithmetic costs more than the trips it saves)
-    for (int e = l; e < TAIL_N * TAIL_N; e += nthr) {
-      const int r = e / TAIL_N, c = e - r * TAIL_N;
+    for (int e = l; e < tcap * tcap; e += nthr) {
+      const int r = e / tcap, c = e - r * tcap;
       const int kn = r / 6, i = r - 6 * kn, jn = kn * h_tail;
       const int kc = c / 6, ic = c - 6 * kc;
       double v = 0.0;
@@ -610,7 +614,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
         else if (kc == kn - 1) v = FR(i * 6 + ic, jn - h_tail);   // H(node kn, node kn-1)[i][ic]
         else if (kc == kn + 1) v = FR(ic * 6 + i, jn);            // H(node kn+1, node kn)[ic][i]
       }
-      SH(tinv, c, r) = v;
+      TINV(c, r) = v;
     }
   }
   CSDO_SYNC();
@@ -622,25 +626,28 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   // side.  For a pivot set P with block-diagonal Pinv and everything else R:
   //   A[P,R] <- Pinv A[P,R];   A[R,R] <- A[R,R] - A[R,P] A[P,R];   A[R,P] <- -A[R,P] Pinv;   A[P,P] <- Pinv
   // (round 4: one pivot block per step, 35 k cycles per inversion; scalar Gauss-Jordan before that: 77 k).
-  double* const pinv = sh.vec;     // 3 x 36 doubles of scratch: the exchange vectors are dead during the factorisation
+  // A tail of up to twelve nodes (BIGT) takes a fourth set: {1, 3, .. 11}, {0, 4, 8}, {2, 10}, {6} - with at most six nodes the
+  // first three are the sets above, the fourth is empty.
+  double* const pinv = sh.vec;     // 3 (BIGT: 6) x 36 doubles of scratch: the exchange vectors are dead during the factorisation
   const int R_nodes = n_tail / 6;
-  for (int grp = 0; grp < 3; ++grp) {
+  for (int grp = 0; grp < (BIGT ? 4 : 3); ++grp) {
     // members of the set: node g0 + k * gs for k < ng
-    const int g0 = (grp == 0) ? 1 : ((grp == 1) ? 0 : 2), gsh = (grp == 0) ? 1 : 2, gs = 1 << gsh;   // (stride 2 or 4: shifts, no division)
+    const int g0 = (grp == 0) ? 1 : ((grp == 1) ? 0 : ((grp == 2) ? 2 : 6)), gsh = (grp == 0) ? 1 : ((grp == 1 || !BIGT) ? 2 : 3),
+              gs = 1 << gsh;   // (stride 2, 4 or 8: shifts, no division)
     const int ng = (g0 < R_nodes) ? (((R_nodes - 1 - g0) >> gsh) + 1) : 0;
     if (ng == 0) continue;
     auto member = [&](const int node) __attribute__((always_inline)) -> int {   // index of the node in the set, or -1
       const int d = node - g0;
       return (d >= 0 && (d & (gs - 1)) == 0 && (d >> gsh) < ng) ? (d >> gsh) : -1;
     };
-    auto node_of = [&](const int rc) __attribute__((always_inline)) -> int {   // rc / 6 for rc < 36
+    auto node_of = [&](const int rc) __attribute__((always_inline)) -> int {   // rc / 6 for rc < 72
       return (rc * 43) >> 8;
     };
     CSDO_TLANES(t) {   // the set's pivot inverses, one lane each: packed lower triangle -> full 6x6 inverse
       if (t < ng) {
         const int p = g0 + t * gs;
         double Ain[21], Pin[21];
-        CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = SH(tinv, 6 * p + c, 6 * p + r); }); });
+        CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = TINV(6 * p + c, 6 * p + r); }); });
         spd_inverse6(Ain, Pin);
         CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { pinv[36 * t + r * 6 + c] = Pin[sym(r, c)]; }); });
       }
@@ -648,17 +655,17 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     CSDO_SYNC();
     CSDO_STHREADS(l, nthr) {   // row blocks: one thread per (member, column outside the set)
       for (int e = l; e < ng * n_tail; e += nthr) {
-        const int k = (e >= n_tail) + (e >= 2 * n_tail), c = e - k * n_tail;
+        const int k = (e >= n_tail) + (e >= 2 * n_tail) + (BIGT ? ((e >= 3 * n_tail) + (e >= 4 * n_tail) + (e >= 5 * n_tail)) : 0), c = e - k * n_tail;
         if (member(node_of(c)) < 0) {
           const int p0 = 6 * (g0 + k * gs);
           double a[6], nw[6];
-          CSDO_FOR(j, 6, { a[j] = SH(tinv, c, p0 + j); });
+          CSDO_FOR(j, 6, { a[j] = TINV(c, p0 + j); });
           CSDO_FOR(i, 6, {
             double v = 0.0;
             CSDO_FOR(j, 6, { v = fma(pinv[36 * k + i * 6 + j], a[j], v); });
             nw[i] = v;
           });
-          CSDO_FOR(i, 6, { SH(tinv, c, p0 + i) = nw[i]; });
+          CSDO_FOR(i, 6, { TINV(c, p0 + i) = nw[i]; });
         }
       }
     }
@@ -667,38 +674,39 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       for (int e = l; e < n_tail * n_tail; e += nthr) {
         const int r = e / n_tail, c = e - r * n_tail;   // (by a float reciprocal instead: 57.49 against 57.07 ms - the allocation, not the division)
         if (member(node_of(r)) < 0 && member(node_of(c)) < 0) {
-          double v = SH(tinv, c, r);
+          double v = TINV(c, r);
           for (int k = 0; k < ng; ++k) {
             const int p0 = 6 * (g0 + k * gs);
-            CSDO_FOR(j, 6, { v = fma(-SH(tinv, p0 + j, r), SH(tinv, c, p0 + j), v); });
+            CSDO_FOR(j, 6, { v = fma(-TINV(p0 + j, r), TINV(c, p0 + j), v); });
           }
-          SH(tinv, c, r) = v;
+          TINV(c, r) = v;
         }
       }
     }
     CSDO_SYNC();
     CSDO_STHREADS(l, nthr) {   // column blocks, and the pivot blocks themselves (the blocks between two members are zero and stay zero)
       for (int e = l; e < ng * n_tail; e += nthr) {
-        const int k = (e >= n_tail) + (e >= 2 * n_tail), r = e - k * n_tail;
+        const int k = (e >= n_tail) + (e >= 2 * n_tail) + (BIGT ? ((e >= 3 * n_tail) + (e >= 4 * n_tail) + (e >= 5 * n_tail)) : 0), r = e - k * n_tail;
         const int p0 = 6 * (g0 + k * gs);
         const int mr = member(node_of(r));
         if (mr < 0) {
           double a[6], nw[6];
-          CSDO_FOR(j, 6, { a[j] = SH(tinv, p0 + j, r); });
+          CSDO_FOR(j, 6, { a[j] = TINV(p0 + j, r); });
           CSDO_FOR(i, 6, {
             double v = 0.0;
             CSDO_FOR(j, 6, { v = fma(-a[j], pinv[36 * k + j * 6 + i], v); });
             nw[i] = v;
           });
-          CSDO_FOR(i, 6, { SH(tinv, p0 + i, r) = nw[i]; });
+          CSDO_FOR(i, 6, { TINV(p0 + i, r) = nw[i]; });
         } else if (mr == k) {
-          CSDO_FOR(i, 6, { SH(tinv, p0 + i, r) = pinv[36 * k + (r - p0) * 6 + i]; });
+          CSDO_FOR(i, 6, { TINV(p0 + i, r) = pinv[36 * k + (r - p0) * 6 + i]; });
         }
       }
     }
     CSDO_SYNC();
   }
 #else
+  static_assert(!BIGT, "a tail of more than six nodes needs the pivot sets");
   // In-place inversion by BLOCK Gauss-Jordan, one 6x6 pivot block per tail node (the pivot blocks of an SPD matrix are SPD:
   // no pivoting).  Scalar Gauss-Jordan was 36 pivots x 2 barriers of mostly latency (77 k cycles per factorisation); this is
   // <= 6 block pivots x 3 barriers.  For pivot block P (rows / columns 6p .. 6p+5) and everything else R:
@@ -708,7 +716,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   const int n_piv = n_tail / 6;
   auto pivot_inverse = [&](const int p) __attribute__((always_inline)) {   // one lane: packed lower triangle -> full 6x6 inverse
     double Ain[21], Pin[21];
-    CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = SH(tinv, 6 * p + c, 6 * p + r); }); });
+    CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = TINV(6 * p + c, 6 * p + r); }); });
     spd_inverse6(Ain, Pin);
     CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { pinv[r * 6 + c] = Pin[sym(r, c)]; }); });
   };
@@ -722,13 +730,13 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       for (int c = l; c < n_tail; c += nthr) {
         if (c < p0 || c >= p0 + 6) {
           double a[6], nw[6];
-          CSDO_FOR(j, 6, { a[j] = SH(tinv, c, p0 + j); });
+          CSDO_FOR(j, 6, { a[j] = TINV(c, p0 + j); });
           CSDO_FOR(k, 6, {
             double v = 0.0;
             CSDO_FOR(j, 6, { v = fma(pinv[k * 6 + j], a[j], v); });
             nw[k] = v;
           });
-          CSDO_FOR(k, 6, { SH(tinv, c, p0 + k) = nw[k]; });
+          CSDO_FOR(k, 6, { TINV(c, p0 + k) = nw[k]; });
         }
       }
     }
@@ -737,9 +745,9 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       for (int e = l; e < n_tail * n_tail; e += nthr) {
         const int r = e / n_tail, c = e - r * n_tail;
         if ((r < p0 || r >= p0 + 6) && (c < p0 || c >= p0 + 6)) {
-          double v = SH(tinv, c, r);
-          CSDO_FOR(k, 6, { v = fma(-SH(tinv, p0 + k, r), SH(tinv, c, p0 + k), v); });
-          SH(tinv, c, r) = v;
+          double v = TINV(c, r);
+          CSDO_FOR(k, 6, { v = fma(-TINV(p0 + k, r), TINV(c, p0 + k), v); });
+          TINV(c, r) = v;
         }
       }
     }
@@ -749,7 +757,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
         double nw[6];
         if (r < p0 || r >= p0 + 6) {
           double a[6];
-          CSDO_FOR(j, 6, { a[j] = SH(tinv, p0 + j, r); });
+          CSDO_FOR(j, 6, { a[j] = TINV(p0 + j, r); });
           CSDO_FOR(k, 6, {
             double v = 0.0;
             CSDO_FOR(j, 6, { v = fma(-a[j], pinv[j * 6 + k], v); });
@@ -758,7 +766,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
         } else {
           CSDO_FOR(k, 6, { nw[k] = pinv[(r - p0) * 6 + k]; });
         }
-        CSDO_FOR(k, 6, { SH(tinv, p0 + k, r) = nw[k]; });
+        CSDO_FOR(k, 6, { TINV(p0 + k, r) = nw[k]; });
       }
     }
     CSDO_SYNC();   // (pinv is still being read above: the next pivot's inverse waits for this barrier)
@@ -784,9 +792,10 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
 #undef PF_R
 #undef XC
 #undef ROW
+#undef TINV
 
 // =========================================================================================================
-template <int ROLE, int MODE, class RowStore, class SolvStore>
+template <int ROLE, int MODE, bool BIGT, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out) {
   AgentDesc ad = B.agents[agent];
@@ -817,7 +826,13 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
   const double sigma = P.sigma, alpha = P.alpha;
   const int n_vars = 6 * Nt - 2;
   int h_tail = 1;                       // BCR levels run for h < h_tail; nodes k * h_tail form the dense tail
-  while ((Nt + h_tail - 1) / h_tail > TAIL_NODES) h_tail <<= 1;
+  // (BIGT kernels: the tail's capacity is the agent's, AgentDesc::tail_nodes - 6, 8 or 12, see dsqp_class.h)
+  const int tail_cap = BIGT ? ((uniform_i32(ad.tail_nodes) > TAIL_NODES) ? uniform_i32(ad.tail_nodes) : (int)TAIL_NODES) : (int)TAIL_NODES;
+  const int ldt = BIGT ? sh.ld_tinv : (int)LD_tinv;      // row stride of the tail's inverse
+  const int tvh = BIGT ? sh.tvec_half : (int)TAIL_N;     // offset of tvec's second half
+  (void)ldt;
+#define TINV(c, r) sh.tinv[(r) * ldt + (c)]
+  while ((Nt + h_tail - 1) / h_tail > tail_cap) h_tail <<= 1;
   const int R_tail = (Nt + h_tail - 1) / h_tail, n_tail = 6 * R_tail;
   int lg_tail = 0;
   while ((1 << lg_tail) < h_tail) ++lg_tail;
@@ -873,9 +888,9 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     S.ncols = (t < Nm) ? 6 : 4;
     S.eqmask = 0;
     S.loosemask = 0;
-    if (t < 2 * TAIL_N) sh.tvec[t] = 0.0;
-    if (t == 0 && Nt < 2 * TAIL_N)
-      for (int k = Nt; k < 2 * TAIL_N; ++k) sh.tvec[k] = 0.0;
+    if (t < 2 * tvh) sh.tvec[t] = 0.0;
+    if (t == 0 && Nt < 2 * tvh)
+      for (int k = Nt; k < 2 * tvh; ++k) sh.tvec[k] = 0.0;
   }
   CSDO_SYNC();
 
@@ -1296,7 +1311,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #else
       const FactorProf fprof{};
 #endif
-      bcr_factor<ROLE, MODE>(sh, rows, rcap, tstart, Nt, h_tail, n_tail, sigma, rho_now, fprof);
+      bcr_factor<ROLE, MODE, BIGT>(sh, rows, rcap, tstart, Nt, h_tail, n_tail, sigma, rho_now, fprof);
     };
 
     // ============================================================== BCR solve on the solver lanes.
@@ -1415,7 +1430,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               // both partials in flight at once: a lane that takes none of the two reads six zeros instead (the hand-over slot of
               // node 0, which has no left neighbours: zero for the whole solve) and subtracts them - b - 0.0 is b - so the wave waits
               // for LDS once per level, not once per side
-              const double* const zeros = sh.tvec + TAIL_N;
+              const double* const zeros = sh.tvec + tvh;
               const double* const pa = (V.fl & (XF_ABS << lev)) ? &SH(pr, 0, t - h) : zeros;
               const double* const pb = (V.fl & (XF_ABSR << lev)) ? &SH(pl, 0, t + h) : zeros;
               double xa[6], xb[6];
@@ -1458,7 +1473,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             constexpr int h = 2 << l6;
             if (h < h_tail) acc += part[l6 + 1];
           });
-          sh.tvec[TAIL_N + 6 * (s >> lg_tail) + q] = acc;
+          sh.tvec[tvh + 6 * (s >> lg_tail) + q] = acc;
         }
       }
       CSDO_XT(2);   // forward levels >= 2
@@ -1474,39 +1489,61 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
       if constexpr (ROLE == ROLE_ROW) {
 #endif
         const int x = CSDO_TID_HOT, wl = x & 63, r = (x >> 6) * 21 + wl / 3, p2 = 2 * (wl % 3);
-        if (x < 128) {
-          double a0 = 0.0, a1 = 0.0;
-          if (wl < 63 && r < n_tail) {
-            double tr0[6], tr1[6], tb0[6], tb1[6];
-            CSDO_FOR(j, 6, {
-              tr0[j] = SH(tinv, 6 * j + p2, r);
-              tr1[j] = SH(tinv, 6 * j + p2 + 1, r);
-              tb0[j] = sh.tvec[6 * j + p2] - sh.tvec[TAIL_N + 6 * j + p2];
-              tb1[j] = sh.tvec[6 * j + p2 + 1] - sh.tvec[TAIL_N + 6 * j + p2 + 1];
-            });
-            CSDO_FOR(j, 6, {
-              a0 = fma(tr0[j], tb0[j], a0);
-              a1 = fma(tr1[j], tb1[j], a1);
-            });
+        // NB blocks of six columns on NW row waves (21 rows of the inverse per wave): 6 on 2 for the six-node tail
+        auto product = [&](auto nb_c, auto nw_c) __attribute__((always_inline)) {
+          constexpr int NB = decltype(nb_c)::value, NW = decltype(nw_c)::value;
+          if (x < 64 * NW) {
+            double a0 = 0.0, a1 = 0.0;
+            if (wl < 63 && r < n_tail) {
+              // (six blocks: all operands in flight at once, as ever; more: four blocks at a time - the row lane's registers are its
+              //  rows' state, and 48 more doubles of operands put that state into scratch)
+              constexpr int CH = NB <= 6 ? NB : 4;
+              CSDO_FOR(c4, NB / CH, {
+                double tr0[CH], tr1[CH], tb0[CH], tb1[CH];
+                CSDO_FOR(jj, CH, {
+                  constexpr int j = c4 * CH + jj;
+                  tr0[jj] = TINV(6 * j + p2, r);
+                  tr1[jj] = TINV(6 * j + p2 + 1, r);
+                  tb0[jj] = sh.tvec[6 * j + p2] - sh.tvec[tvh + 6 * j + p2];
+                  tb1[jj] = sh.tvec[6 * j + p2 + 1] - sh.tvec[tvh + 6 * j + p2 + 1];
+                });
+                CSDO_FOR(jj, CH, {
+                  a0 = fma(tr0[jj], tb0[jj], a0);
+                  a1 = fma(tr1[jj], tb1[jj], a1);
+                });
+                if constexpr (NB > 6) CSDO_STAGE();
+              });
+            }
+            const double s01 = a0 + a1;
+            const double up1 = wave_next(s01), up2 = wave_next(up1);
+            const double s0123 = s01 + up1;
+            const double tot = s0123 + up2;
+            if (wl < 63 && r < n_tail && p2 == 0) {
+              const int kn = r / 6, i = r - 6 * kn;
+              sh.vec[(kn * h_tail) * LD_vec + i] = tot;
+            }
           }
-          const double s01 = a0 + a1;
-          const double up1 = wave_next(s01), up2 = wave_next(up1);
-          const double s0123 = s01 + up1;
-          const double tot = s0123 + up2;
-          if (wl < 63 && r < n_tail && p2 == 0) {
-            const int kn = r / 6, i = r - 6 * kn;
-            sh.vec[(kn * h_tail) * LD_vec + i] = tot;
-          }
+        };
+        if constexpr (!BIGT) {
+          product(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
+        } else {   // (the blocks beyond the agent's tail are zeros - rows and rhs -: they add +0.0)
+          if (tail_cap <= 6) product(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
+          else if (tail_cap <= 8) product(std::integral_constant<int, 8>{}, std::integral_constant<int, 3>{});
+          else product(std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
         }
       }
       if constexpr (ROLE == ROLE_BOTH)
 #endif
       CSDO_TLANES_TOP(t) {
         double a4[6] = {0, 0, 0, 0, 0, 0};
+        if constexpr (BIGT) {   // (the tail's size is the agent's: block after block of six columns, the same chains)
+          for (int c0 = 0; c0 < ldt - 2; c0 += 6)
+            CSDO_FOR(i6, 6, { a4[i6] = fma(TINV(c0 + i6, t), sh.tvec[c0 + i6] - sh.tvec[tvh + c0 + i6], a4[i6]); });
+        } else
         CSDO_FOR(q, 4, {
           double tr[TAIL_N / 4], tb[TAIL_N / 4];
           CSDO_FOR(c, TAIL_N / 4, {
-            tr[c] = SH(tinv, q * (TAIL_N / 4) + c, t);
+            tr[c] = TINV(q * (TAIL_N / 4) + c, t);
             tb[c] = sh.tvec[q * (TAIL_N / 4) + c] - sh.tvec[TAIL_N + q * (TAIL_N / 4) + c];
           });
           CSDO_FOR(c, TAIL_N / 4, { a4[(q * (TAIL_N / 4) + c) % 6] = fma(tr[c], tb[c], a4[(q * (TAIL_N / 4) + c) % 6]); });
@@ -1740,8 +1777,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (wl < 63 && r < n_tail) {
             double tr0[6], tr1[6], tb0[6], tb1[6];
             CSDO_FOR(j, 6, {
-              tr0[j] = SH(tinv, 6 * j + p2, r);
-              tr1[j] = SH(tinv, 6 * j + p2 + 1, r);
+              tr0[j] = TINV(6 * j + p2, r);
+              tr1[j] = TINV(6 * j + p2 + 1, r);
               tb0[j] = sh.tvec[6 * j + p2];
               tb1[j] = sh.tvec[6 * j + p2 + 1];
             });
@@ -1768,10 +1805,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         {
           // columns >= n_tail of the inverse rows and of the gathered rhs are zero: no per-column test needed
           double a4[6] = {0, 0, 0, 0, 0, 0};
+          if constexpr (BIGT) {
+            for (int c0 = 0; c0 < ldt - 2; c0 += 6)
+              CSDO_FOR(i6, 6, { a4[i6] = fma(TINV(c0 + i6, t), sh.tvec[c0 + i6], a4[i6]); });
+          } else
           CSDO_FOR(q, 4, {     // quarters of the row: the solver lanes' registers hold their node's factor
             double tr[TAIL_N / 4], tb[TAIL_N / 4];
             CSDO_FOR(c, TAIL_N / 4, {
-              tr[c] = SH(tinv, q * (TAIL_N / 4) + c, t);
+              tr[c] = TINV(q * (TAIL_N / 4) + c, t);
               tb[c] = sh.tvec[q * (TAIL_N / 4) + c];
             });
             CSDO_FOR(c, TAIL_N / 4, { a4[(q * (TAIL_N / 4) + c) % 6] = fma(tr[c], tb[c], a4[(q * (TAIL_N / 4) + c) % 6]); });

@@ -10,6 +10,7 @@
 
 #include "../../csdotrajectoryplanning_amd/csrc/batch_pack.h"
 #include "../../csdotrajectoryplanning_amd/csrc/dsqp_program.h"
+#include "../../csdotrajectoryplanning_amd/csrc/dsqp_class.h"
 
 using namespace csdo;
 
@@ -23,7 +24,13 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
   HostBatch hb;
   const int rc = pack_worlds(worlds, n_worlds, hb);
   if (rc != CSDO_OK) return rc;
-  for (auto& ad : hb.agents) ad.rows_lds = rows_lds ? 1 : 0;
+  for (auto& ad : hb.agents) {
+    ad.rows_lds = rows_lds ? 1 : 0;
+    // the tail's capacity: the launcher's rule (dsqp_class.h), whatever residency mode this call emulates
+    int m_ = 0, r_ = 0, tail_ = TAIL_NODES;
+    dsqp_agent_class(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, &m_, &r_, &tail_);
+    ad.tail_nodes = tail_;
+  }
   const int Na = (int)hb.agents.size();
   std::vector<double> rows_ws((size_t)std::max<int64_t>(hb.rows_total, 1) * ROWS_WS_STRIDE, 0.0);
   std::vector<double> fac_ws((size_t)hb.fac_total, 0.0);
@@ -54,7 +61,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     const int st = fac_stride(ad.Nt);
     // the same carve as dsqp_kernel_body.h (mode 0: bounds + the factor's LDS part in "LDS", rows' state too when
     // AgentDesc::rows_lds; 1: without the factor part; 3: lean)
-    std::vector<double> lds((size_t)LD_block * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N + TAIL_N * 38 +
+    std::vector<double> lds((size_t)LD_block * st + 3 * hb.max_obs + 2 + 32 + 2 * TAIL_N_BIG + TAIL_N_BIG * (TAIL_N_BIG + 2) +
                             (size_t)(3 + LD_prow) * hb.max_planes + 4 + 16 * 8, 0.0);
     std::vector<double> pc_ws((size_t)3 * hb.max_planes + 1, 0.0);
     Shm sh{};
@@ -86,10 +93,13 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     sh.obs = rest;
     sh.bcast = sh.obs + ((3 * hb.max_obs + 1) & ~1);
     sh.tvec = sh.bcast + 32;
-    sh.tinv = sh.tvec + 2 * TAIL_N;
+    const int tcap_ = ad.tail_nodes > TAIL_NODES ? 6 * ad.tail_nodes : TAIL_N;
+    sh.tvec_half = ad.tail_nodes > TAIL_NODES ? TAIL_N_BIG : TAIL_N;
+    sh.ld_tinv = tcap_ + 2;
+    sh.tinv = sh.tvec + 2 * sh.tvec_half;
     sh.pcg = pc_ws.data();
     if (mode == 0) {
-      sh.pc = sh.tinv + TAIL_N * 38;
+      sh.pc = sh.tinv + tcap_ * (tcap_ + 2);
       sh.prow = sh.pc + ((3 * hb.max_planes + 1) & ~1);
       sh.pco = sh.prow + (size_t)LD_prow * hb.max_planes;   // room for the coefficients of 8 planes: both paths of the
       sh.n_pco = std::min<int>(8, ad.n_planes) & ~1;         // plane pass (LDS copy / workspace) run in every test
@@ -99,12 +109,12 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     sh.facX = sh.facE + (size_t)FAC_E_DOUBLES * st;
     sh.cold = sh.facX + (size_t)FAC_X_DOUBLES * st;
     std::vector<RowRegs> lanes_r(ad.Nt);
-    std::vector<SolvRegs> lanes_s(std::max<int>(ad.Nt + 2, TAIL_N));   // (+ the partner lane of a last, even node)
+    std::vector<SolvRegs> lanes_s(std::max<int>(ad.Nt + 2, TAIL_N_BIG));   // (+ the partner lane of a last, even node)
     ProgramOut po{};
-    if (mode == 0) agent_program<ROLE_BOTH, 0>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-    else if (mode == 1) agent_program<ROLE_BOTH, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-    else if (mode == 2) agent_program<ROLE_BOTH, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-    else agent_program<ROLE_BOTH, 3>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    if (mode == 0) agent_program<ROLE_BOTH, 0, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else if (mode == 1) agent_program<ROLE_BOTH, 1, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else if (mode == 2) agent_program<ROLE_BOTH, 2, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else agent_program<ROLE_BOTH, 3, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     sqp[a] = po.sqp_iters;
     admm[a] = po.admm_iters;
     stat[a] = po.last_status;

@@ -66,6 +66,7 @@ def lib():
                                                    PP(abi.BridgeOut)]
         L.csdo_dsqp_last_limit.argtypes = [H, PP(C.c_int32), PP(C.c_int32), PP(C.c_int64)]
         L.csdo_dsqp_estimate_work.argtypes = [PP(abi.Problem), C.c_int32, abi.c_double_p]
+        L.csdo_dsqp_agent_class.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.csdo_validate.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                     C.c_double, C.POINTER(abi.Vehicle), C.c_double, C.POINTER(abi.Validation)]
         L.csdo_validate_frames.argtypes = [H, abi.c_double_p, C.c_int32, C.c_int32, C.c_int32, abi.c_double_p, C.c_int32,

@@ -685,6 +685,17 @@ int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double
   }
 }
 
+int csdo_dsqp_agent_class(int32_t Nt, int32_t n_obstacles, int32_t n_planes, int64_t out[5]) {
+  if (!out || Nt < 2 || Nt > CSDO_MAX_NT || n_obstacles < 0 || n_planes < 0) return CSDO_EINVAL;
+  int mode = 0, rows = 0, tail = TAIL_NODES;
+  out[0] = dsqp_agent_class(Nt, n_obstacles, n_planes, &mode, &rows, &tail);
+  out[1] = mode;
+  out[2] = rows;
+  out[3] = tail;
+  out[4] = (int64_t)dsqp_lds_bytes(Nt, n_obstacles, n_planes, mode, rows != 0, tail);
+  return CSDO_OK;
+}
+
 int csdo_dsqp_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
   if (h && h->multi) return guarded([&]() { return multi_upload(h, worlds, n_worlds); });
   return guarded([&]() { return upload_impl(h, worlds, n_worlds); });

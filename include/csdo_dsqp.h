@@ -218,6 +218,14 @@ int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
  * from: horizon, plane count and how much of the initial guess sits in tight spots), in upload order; host code, no GPU
  * needed.  For sharding a batch over GPUs by work instead of by agent count. */
 int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double* est /* [sum Na] */);
+/* The kernel class one agent runs in, from its horizon, the obstacle count of its world and its number of inter-vehicle planes (host
+ * code, no GPU needed): out[0] threads per workgroup (256 / 512 / 768 / 1024), out[1] LDS residency mode, out[2] whether the
+ * inter-vehicle rows' state fits LDS, out[3] capacity of the dense tail of the block cyclic reduction in 6x6 nodes (6, or 8 for
+ * horizons of the 512-thread class that lose a level by it), out[4] LDS bytes of that working set (above the per-workgroup limit of
+ * 163776: such a world is turned away with CSDO_ELIMIT).  Everything but out[3] only decides the speed; the tail's capacity also
+ * decides the elimination order of the last nodes, i.e. last bits - it depends on the agent alone, so results do not depend on how
+ * agents are batched, chunked or sharded. */
+int csdo_dsqp_agent_class(int32_t Nt, int32_t n_obstacles, int32_t n_planes, int64_t out[5]);
 /* Device pointer to the packed solutions of the last run ([sum Na][Nt_stride][6] doubles) for collectives. */
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles);
 

@@ -170,6 +170,17 @@ extern "C" int csdo_emu_generate_boxes(const double* pts, int32_t n, const doubl
 }
 
 // the shared trigonometry (csrc/csdo_math.h) as this host build compiles it; fn 0 sin, 1 cos, 2 tan, 3 atan2(a, b); 10..13: the C library's
+// the class rule as this build applies it (dsqp_class.h): block, mode, rows_lds, tail nodes
+extern "C" int csdo_emu_agent_class(int32_t nt, int32_t n_obs, int32_t n_planes, int64_t* out) {
+  int mode = 0, rows = 0, tail = TAIL_NODES;
+  out[0] = dsqp_agent_class(nt, n_obs, n_planes, &mode, &rows, &tail);
+  out[1] = mode;
+  out[2] = rows;
+  out[3] = tail;
+  out[4] = (int64_t)dsqp_lds_bytes(nt, n_obs, n_planes, mode, rows != 0, tail);
+  return 0;
+}
+
 extern "C" int csdo_emu_math_eval(int32_t fn, const double* a, const double* b, double* out, int32_t n) {
   for (int i = 0; i < n; ++i) {
     switch (fn) {

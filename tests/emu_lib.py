@@ -28,6 +28,7 @@ def lib():
         _LIB.csdo_emu_generate_boxes.argtypes = [abi.c_double_p, C.c_int32, abi.c_double_p, C.c_int32, C.c_double,
                                                  C.c_double, C.POINTER(abi.Vehicle), abi.c_double_p, abi.c_int32_p]
         _LIB.csdo_emu_math_eval.argtypes = [C.c_int32, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_int32]
+        _LIB.csdo_emu_agent_class.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     return _LIB
 
 
@@ -71,3 +72,10 @@ def generate_boxes(points, obstacles, dimx, dimy, veh):
     lib().csdo_emu_generate_boxes(abi.as_double_p(points), n, abi.as_double_p(obstacles), obstacles.shape[0], dimx,
                                   dimy, C.byref(veh), abi.as_double_p(boxes), abi.as_int32_p(status))
     return boxes, status
+
+
+def agent_class(nt, n_obs, n_planes):
+    """(threads, mode, rows_lds, tail_nodes, lds_bytes) as this build's class rule gives them (csrc/dsqp_class.h)."""
+    out = (C.c_int64 * 5)()
+    assert lib().csdo_emu_agent_class(nt, n_obs, n_planes, out) == 0
+    return tuple(int(v) for v in out)

@@ -111,6 +111,9 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
 // The 256-thread class (horizons <= 128) is built for two workgroups per CU: a workgroup's waves spend most of a step waiting
 // for LDS round trips and barriers (scripts/microbench2.hip), a second agent on the same SIMDs fills those gaps; its working
 // set (<= 80 KB of LDS, 256 registers per lane) allows it.  The 512-thread class fills the register file by itself.
+#if !defined(CSDO_PRIO_SOLVER)
+#define CSDO_PRIO_SOLVER 2
+#endif
 template <int BLOCK, int MODE, bool SPLIT>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kernel(const DeviceBatch B, const int first, const int count,
                                                              int* __restrict__ queue, const int lds_doubles) {
@@ -118,6 +121,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
   __shared__ int next_in_queue;
   static_assert(SPLIT, "one thread per timestep playing both roles is only built lane-serially (tests/emu)");
   if (threadIdx.x < BLOCK / 2) {        // row waves
+#if defined(CSDO_PRIO_ROW)
+    __builtin_amdgcn_s_setprio(CSDO_PRIO_ROW);   // experiment: the row waves' instructions first where both roles have work (the update)
+#endif
     for (;;) {
       if (threadIdx.x == 0) next_in_queue = atomicAdd(queue, 1);
       __syncthreads();
@@ -148,6 +154,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
       }
     }
   } else {                              // solver waves
+    // The solver waves' instructions go first wherever a SIMD's two waves - one of each role - both have something to issue: every
+    // ADMM iteration's critical path runs through the solver waves, the row waves' work beside it (tail product, prefetches) has
+    // slack.  One s_setprio per workgroup (levels 1, 2, 3 measure the same; the row waves raised instead: no change): map100 53.9 ->
+    // 53.3 ms, room50 36.7 -> 36.2, agents100 47.3 -> 46.3, one 50-agent instance alone 8.85 -> 8.3 ms.  Same bits.
+    __builtin_amdgcn_s_setprio(CSDO_PRIO_SOLVER);
     for (;;) {
       __syncthreads();
       const int q_idx = uniform_i32(next_in_queue);

@@ -10,10 +10,12 @@ its ADMM QPs) over one batch of worlds whose inputs are already resident in HBM.
            synth1024  (configs[4]) 21 worlds (ex0..ex20 of the map100 set) truncated to 1024 agents
            room50     benchmark/room/agents50 ex0..ex11: 238 obstacles per world (the obstacle-dense regime)
            agents100  benchmark/map100by100/agents100/obstacle ex0..ex11: 100 vehicles per world (the plane-dense regime)
---gpus N > 1 without WORLD_SIZE in the environment: bench.py starts the N ranks ITSELF - a child `python -m torch.distributed.run
---nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <the same arguments>`, started before this process has touched the
+--gpus N > 1 outside torch.distributed.run: bench.py starts the N ranks ITSELF - a child `python -m torch.distributed.run --standalone
+--local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N bench.py <the same arguments>`, started before this process has touched the
 GPU, rank 0's JSON line comes through on the shared stdout, the exit code is the children's.  Launched under torch.distributed.run
-(WORLD_SIZE set, as the driver does for N > 1) it is one of the ranks and insists on WORLD_SIZE == --gpus.
+(RANK and WORLD_SIZE set, as the driver does for N > 1) it is one of the ranks: --gpus left out adopts WORLD_SIZE, --gpus given must
+equal it.  For N > 1 the line carries BOTH scaling curves: `value` is --scaling's job, `value_weak` / `value_strong` the other's
+(a second timed loop of the same K steps).
 N > 1 ranks (one process per GPU, RCCL):
 Either way the agents of the job are SHARDED by sharding.shard_batch_plan: rank r owns one contiguous block of the job's
 concatenated agents (the reference's loop over agents is what shards, sqp/dsqp_solver.cc:1198-1220), builds only the worlds
@@ -103,9 +105,11 @@ def effective_cpus():
     return n
 
 
-def _newest_pmc(workload, step_ms):
-    """HBM traffic / VALU figures of the dominant kernel from the newest committed PMC summary, or Nones if it does not
-    describe this workload at (about) this speed."""
+def _newest_pmc(workload, step_ms, lib_hash):
+    """HBM traffic / VALU figures of the dominant kernel from the newest committed PMC summary of this workload - but only if that
+    summary was taken from THE KERNEL THAT IS RUNNING: its `kernel_source_hash` (scripts/summarize_profiles.py) must equal the
+    library's csdo_source_hash(), and its step time must be within 20 % of this run's.  Otherwise Nones and the reason: counters of
+    another build are not evidence for this one."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     for path in reversed(files):
         try:
@@ -115,18 +119,23 @@ def _newest_pmc(workload, step_ms):
             continue
         if d.get("workload", "map100") != workload:
             continue
+        name = os.path.basename(path)
+        if d.get("kernel_source_hash") != lib_hash:
+            return None, None, None, name + " (not quoted: taken from kernel sources %s, this library is %s)" % (
+                d.get("kernel_source_hash", "without a hash"), lib_hash)
         ref_ms = d.get("ms_per_step")      # span of all agent-kernel dispatches of a step in the profiled run
         if ref_ms and abs(ref_ms - step_ms) > 0.2 * step_ms:
-            return None, None, None, os.path.basename(path) + " (stale: %.1f ms per step there)" % ref_ms
+            return None, None, None, name + " (stale: %.1f ms per step there)" % ref_ms
         return (d.get("hbm_bytes_per_launch_dominant_kernel"), d.get("hbm_counter_frac_of_peak"),
-                d.get("valu_fp64_issue_frac"), os.path.basename(path))
+                d.get("valu_fp64_issue_frac"), name)
     return None, None, None, None
 
 
-def _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong):
+def _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong, other=None):
     """--dry: the N-rank step on the CPU - gloo group, this rank's block solved by the lane-serial host build of the device program
     (tests/emu, test infrastructure), FlatGather.stage / collect as in the GPU step - and rank 0's line.  Nothing here is timed as a
-    result: `value` is null."""
+    result: `value` is null.  N > 1: the other scaling's job runs the same way behind the first (`other_scaling`)."""
+    import hashlib
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -136,26 +145,36 @@ def _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong)
     os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
     dev = torch.device("cpu")
-    n_dbl = int(sum(w.Na * w.Nt * 6 for w in worlds))
-    fg = sharding.FlatGather(n_dbl, dist, dev)
-    iters_step, local = 0, None
+
+    def job(job_worlds):
+        n_dbl = int(sum(w.Na * w.Nt * 6 for w in job_worlds))
+        fg = sharding.FlatGather(n_dbl, dist, dev)
+        iters_step, local = 0, None
+        for _ in range(args.warmup + args.steps):
+            sols = emu_lib.solve_batch(job_worlds, 0, max(1, (os.cpu_count() or 2) // world_size)) if job_worlds else []
+            local = torch.from_numpy(np.concatenate([s.solutions.reshape(-1) for s in sols]) if sols else np.zeros(0))
+            fg.stage(local)
+            fg.collect()
+            iters_step = int(sum(int(s.admm_iters.sum()) for s in sols))
+        mine = fg.parts()[rank]
+        ok = bool(torch.equal(mine, local)) and fg.lengths[rank] == n_dbl
+        t = torch.tensor([float(iters_step), float(sum(w.Na for w in job_worlds)), float(ok)], dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world_size)]
+        dist.all_gather(allr, t)
+        sha = hashlib.sha256(np.concatenate([p.numpy() for p in fg.parts()]).tobytes()).hexdigest() if rank == 0 else None
+        return allr, sha, int(sum(fg.lengths))
+
     t0 = time.perf_counter()
-    for _ in range(args.warmup + args.steps):
-        sols = emu_lib.solve_batch(worlds, 0, max(1, (os.cpu_count() or 2) // world_size))
-        local = torch.from_numpy(np.concatenate([s.solutions.reshape(-1) for s in sols]) if sols else np.zeros(0))
-        fg.stage(local)
-        fg.collect()
-        iters_step = int(sum(int(s.admm_iters.sum()) for s in sols))
+    allr, gathered_sha, gathered = job(worlds)
+    other_line = None
+    if other is not None:
+        o_jobs, o_sizes, _, _, o_worlds, _, _ = other
+        o_allr, o_sha, o_gathered = job(o_worlds)
+        other_line = {"scaling": "weak" if strong else "strong", "value": None, "worlds_total": len(o_jobs),
+                      "agents_total": int(sum(o_sizes)), "gathered_doubles": o_gathered, "gathered_sha256": o_sha,
+                      "per_rank": [{"rank": r, "agents": int(v[1]), "admm_iterations_per_step": int(v[0]),
+                                    "gathered_block_equals_local": bool(v[2])} for r, v in enumerate(o_allr)]}
     elapsed = time.perf_counter() - t0
-    mine = fg.parts()[rank]
-    ok = bool(torch.equal(mine, local)) and fg.lengths[rank] == n_dbl
-    t = torch.tensor([float(iters_step), float(sum(w.Na for w in worlds)), float(ok)], dtype=torch.float64)
-    allr = [torch.zeros_like(t) for _ in range(world_size)]
-    dist.all_gather(allr, t)
-    gathered_sha = None
-    if rank == 0:
-        import hashlib
-        gathered_sha = hashlib.sha256(np.concatenate([p.numpy() for p in fg.parts()]).tobytes()).hexdigest()
     n_ranks = dist.get_world_size()
     dist.barrier()
     dist.destroy_process_group()
@@ -164,17 +183,19 @@ def _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong)
             "metric": "agent_qp_iterations_per_sec", "value": None, "unit": "agent-QP-iterations/s", "dry": True,
             "n_gpus": n_ranks, "rccl_ranks": None, "gloo_ranks": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            ("value_weak" if strong else "value_strong"): None, "other_scaling": other_line,
             "dtype": "f64", "data": "dry run on the CPU (lane-serial host build of the device program): plumbing only, no measurement",
             "config": {"workload_key": args.workload, "worlds_total": len(jobs), "agents_total": int(sum(sizes)),
                        "per_rank": [{"rank": r, "agents": int(v[1]), "admm_iterations_per_step": int(v[0]),
                                      "gathered_block_equals_local": bool(v[2])} for r, v in enumerate(allr)],
-                       "shard_balance": shard_balance, "gathered_doubles": int(sum(fg.lengths)),
+                       "shard_balance": shard_balance, "gathered_doubles": gathered,
                        "gathered_sha256": gathered_sha, "wall_s": elapsed}}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of the job (default: WORLD_SIZE under torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=("map100", "map50", "synth1024", "room50", "agents100"), default="map100")
@@ -198,24 +219,30 @@ def main():
                     help="CPU check of the multi-rank plumbing: gloo, no GPU, the lane-serial host build as the solver; not a measurement")
     args = ap.parse_args()
 
+    # Under torch.distributed.run (RANK and WORLD_SIZE set: the driver's launch for N > 1) this process is one of the ranks: --gpus left
+    # out adopts WORLD_SIZE, --gpus given must equal it.  Otherwise (a stray WORLD_SIZE without RANK counts for nothing) --gpus N > 1
+    # starts the N ranks here.
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus is None:
+        args.gpus = int(os.environ["WORLD_SIZE"]) if under_launcher else 1
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and not under_launcher:
         # One process per GPU, started HERE: fresh children (no exec of this process, which must not have touched the GPU - it has
         # not: nothing above imports torch or the library), rank 0's line on the inherited stdout, the children's exit code.
-        import socket
+        # --standalone: the launcher binds its own rendezvous port (port 0) - no port probed here and taken by someone else before
+        # torchrun binds it; --local-addr: the container's hostname may not resolve.
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env["OMP_NUM_THREADS"] = os.environ.get("OMP_NUM_THREADS", "1")
         sys.stdout.flush()
-        sys.exit(subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))).returncode)
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    world_size = int(os.environ["WORLD_SIZE"]) if under_launcher else 1
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or without "
                          "torch.distributed.run: bench.py starts its ranks itself)" % (args.gpus, world_size))
@@ -231,10 +258,6 @@ def main():
     from multiprocessing import get_context
     from csdotrajectoryplanning_amd import sharding, workloads
     t_pre0 = time.perf_counter()
-    jobs = []
-    for c in range(copies):
-        jobs += workloads.workload_jobs(args.workload, args.instances, seed_offset=60 * c, front=args.front)
-    sizes = [workloads.job_agents(j) for j in jobs]
 
     def _build_all(js):
         procs = min(len(js), os.cpu_count() or 1, max(args.setup_procs, 1))
@@ -243,45 +266,61 @@ def main():
                 return pool.map(_build, js)
         return [_build(j) for j in js]
 
-    shard_balance = None
-    if sharded:
-        # blocks of equal estimated WORK (the launcher's own estimate), not of equal agent count: every rank builds copy 0 of the
-        # workload for the estimates (the copies of a weak-scaling job differ only in the seeds of the few stand-in worlds)
-        import numpy as _np
-        from csdotrajectoryplanning_amd.solver import estimate_work
-        base = jobs[:len(jobs) // copies]
-        built0 = _build_all(base)
-        est = _np.tile(estimate_work([w for w, _ in built0]), copies)
-        plan = sharding.shard_batch_plan(sizes, rank, world_size, weights=est)
-        loads = [float(est[lo:hi].sum()) for lo, hi in sharding.shard_bounds_weighted(est, world_size)]
-        by_count = [float(est[lo:hi].sum()) for lo, hi in sharding.shard_bounds(len(est), world_size)]
-        shard_balance = {"estimated_work_max_over_mean": max(loads) / (sum(loads) / len(loads)),
-                         "if_balanced_by_agent_count": max(by_count) / (sum(by_count) / len(by_count))}
-        my_jobs = [jobs[w] for w, _, _ in plan]
-        built = []
-        todo = []
-        for w, _, _ in plan:
-            c, k = divmod(w, len(base))
-            if c == 0 or str(built0[k][1]["generator"]).startswith("front_end"):
-                built.append(built0[k])
-            else:
-                built.append(None)
-                todo.append((len(built) - 1, jobs[w]))
-        for (slot, _), b in zip(todo, _build_all([j for _, j in todo]) if todo else []):
-            built[slot] = b
-    else:
-        plan = [(w, 0, n) for w, n in enumerate(sizes)]
-        my_jobs = [jobs[w] for w, _, _ in plan]
-        built = _build_all(my_jobs)
-    worlds, infos = [], []
-    for (w, lo, hi), (world, info) in zip(plan, built):
-        worlds.append(world if (lo == 0 and hi == world.Na) else world.subset(lo, hi))
-        infos.append(info)
+    built0_cache = [None]
+
+    def build_rank_job(n_copies):
+        """This rank's share of a job of `n_copies` copies of the workload: (jobs, sizes, plan, my_jobs, worlds, infos, shard_balance)."""
+        jobs_ = []
+        for c in range(n_copies):
+            jobs_ += workloads.workload_jobs(args.workload, args.instances, seed_offset=60 * c, front=args.front)
+        sizes_ = [workloads.job_agents(j) for j in jobs_]
+        balance = None
+        if sharded:
+            # blocks of equal estimated WORK (the launcher's own estimate), not of equal agent count: every rank builds copy 0 of the
+            # workload for the estimates (the copies of a weak-scaling job differ only in the seeds of the few stand-in worlds)
+            import numpy as _np
+            from csdotrajectoryplanning_amd.solver import estimate_work
+            base = jobs_[:len(jobs_) // n_copies]
+            if built0_cache[0] is None:
+                built0_cache[0] = _build_all(base)
+            built0 = built0_cache[0]
+            est = _np.tile(estimate_work([w for w, _ in built0]), n_copies)
+            plan_ = sharding.shard_batch_plan(sizes_, rank, world_size, weights=est)
+            loads = [float(est[lo:hi].sum()) for lo, hi in sharding.shard_bounds_weighted(est, world_size)]
+            by_count = [float(est[lo:hi].sum()) for lo, hi in sharding.shard_bounds(len(est), world_size)]
+            balance = {"estimated_work_max_over_mean": max(loads) / (sum(loads) / len(loads)),
+                       "if_balanced_by_agent_count": max(by_count) / (sum(by_count) / len(by_count))}
+            my_jobs_ = [jobs_[w] for w, _, _ in plan_]
+            built = []
+            todo = []
+            for w, _, _ in plan_:
+                c, k = divmod(w, len(base))
+                if c == 0 or str(built0[k][1]["generator"]).startswith("front_end"):
+                    built.append(built0[k])
+                else:
+                    built.append(None)
+                    todo.append((len(built) - 1, jobs_[w]))
+            for (slot, _), b in zip(todo, _build_all([j for _, j in todo]) if todo else []):
+                built[slot] = b
+        else:
+            plan_ = [(w, 0, n) for w, n in enumerate(sizes_)]
+            my_jobs_ = [jobs_[w] for w, _, _ in plan_]
+            built = _build_all(my_jobs_)
+        worlds_, infos_ = [], []
+        for (w, lo, hi), (world, info) in zip(plan_, built):
+            worlds_.append(world if (lo == 0 and hi == world.Na) else world.subset(lo, hi))
+            infos_.append(info)
+        return jobs_, sizes_, plan_, my_jobs_, worlds_, infos_, balance
+
+    jobs, sizes, plan, my_jobs, worlds, infos, shard_balance = build_rank_job(copies)
+    # N > 1: the OTHER scaling's job too, so that one line carries both curves (`value` is --scaling's, `value_weak` / `value_strong`
+    # the other's; two timed loops)
+    other = build_rank_job(world_size if strong else 1) if world_size > 1 else None
     t_pre = time.perf_counter() - t_pre0
 
     import numpy as np
     if args.dry:
-        return _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong)
+        return _dry_run(args, rank, world_size, worlds, jobs, sizes, shard_balance, strong, other)
     from csdotrajectoryplanning_amd.solver import DsqpHandle, interpolate_and_planes
     n_front = sum(1 for i in infos if str(i["generator"]).startswith("front_end"))
     guesses = ("initial guesses: %d worlds from this repository's front end (PBS over hybrid A*, paths stored by "
@@ -369,65 +408,91 @@ def main():
                         "obstacle_collision_triples": prep.obstacle_collisions, "out_of_map": prep.out_of_map}
 
     # ---- the batch ----
-    t_u0 = time.perf_counter()
-    h.upload(worlds)
-    t_upload_first = time.perf_counter() - t_u0
-    ptr, n_dbl = h.device_solutions()
-    sol_dev = torch.as_tensor(_DevArray(ptr, n_dbl), device=dev)
-    fg = None
-    if sharded:
-        with torch.cuda.stream(tstream):
-            fg = sharding.FlatGather(n_dbl, dist, dev)     # ranks differ in sum(Nt): padded to the largest
-        tstream.synchronize()
-
     # Sharded step: solve enqueued (csdo_dsqp_run_async), the copy out of the solver's buffer ordered behind it on the same stream,
     # the all-gather on a SECOND stream behind that copy - so the collective of step k runs beside the solve of step k + 1 (the
     # next copy into the send buffer waits for it).  The barrier / synchronize pair around the timed region covers both streams.
-    gstream = torch.cuda.Stream(device=dev) if fg is not None else None
-    collected = [None]
+    gstream = torch.cuda.Stream(device=dev) if sharded else None
 
-    def step():
-        if fg is None:
-            return h.run(stream)
-        h.run_async(stream)
-        with torch.cuda.stream(tstream):
-            if collected[0] is not None:
-                tstream.wait_event(collected[0])
-            fg.stage(sol_dev)
-            staged = tstream.record_event()
-        with torch.cuda.stream(gstream):
-            gstream.wait_event(staged)
-            fg.collect()
-            collected[0] = gstream.record_event()
-        return h.wait()
+    def timed_job(job_worlds):
+        """Upload, W warm-up steps, K timed steps between barrier + synchronize pairs, download: one job of this rank."""
+        t_u0 = time.perf_counter()
+        h.upload(job_worlds)
+        t_up = time.perf_counter() - t_u0
+        ptr, n_dbl = h.device_solutions()
+        sol_dev = torch.as_tensor(_DevArray(ptr, n_dbl), device=dev)
+        fg = None
+        if sharded:
+            with torch.cuda.stream(tstream):
+                fg = sharding.FlatGather(n_dbl, dist, dev)     # ranks differ in sum(Nt): padded to the largest
+            tstream.synchronize()
+        collected = [None]
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kernel_s = 0.0
-    group_s = None
-    for _ in range(args.steps):
-        kernel_s += step()
-        gs = [g["seconds"] for g in h.launch_groups()]
-        group_s = gs if group_s is None else [a + b for a, b in zip(group_s, gs)]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        def step():
+            if fg is None:
+                return h.run(stream)
+            h.run_async(stream)
+            with torch.cuda.stream(tstream):
+                if collected[0] is not None:
+                    tstream.wait_event(collected[0])
+                fg.stage(sol_dev)
+                staged = tstream.record_event()
+            with torch.cuda.stream(gstream):
+                gstream.wait_event(staged)
+                fg.collect()
+                collected[0] = gstream.record_event()
+            return h.wait()
 
-    t_d0 = time.perf_counter()
-    sols = h.download()
-    t_download = time.perf_counter() - t_d0
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k_s, g_s = 0.0, None
+        for _ in range(args.steps):
+            k_s += step()
+            gs = [g["seconds"] for g in h.launch_groups()]
+            g_s = gs if g_s is None else [a + b for a, b in zip(g_s, gs)]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        t_d0 = time.perf_counter()
+        job_sols = h.download()
+        return {"elapsed": el, "kernel_s": k_s, "group_s": g_s, "sols": job_sols, "t_upload": t_up,
+                "t_download": time.perf_counter() - t_d0}
+
+    def over_ranks(el, iters):
+        """(max over ranks of the elapsed time, sum over ranks of the iterations per step)"""
+        if dist is None:
+            return el, float(iters)
+        t = torch.tensor([el, float(iters)], dtype=torch.float64, device=dev)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[1])
+
+    main_job = timed_job(worlds)
+    elapsed, kernel_s, group_s, sols = main_job["elapsed"], main_job["kernel_s"], main_job["group_s"], main_job["sols"]
+    t_upload_first, t_download = main_job["t_upload"], main_job["t_download"]
     iters_step = int(sum(int(s.admm_iters.sum()) for s in sols))
     groups = h.launch_groups()
     group_of = h.agent_groups()
     bytes_agent = np.concatenate([algorithmic_bytes(w, s.admm_iters) for w, s in zip(worlds, sols)])
     iters_agent = np.concatenate([s.admm_iters for s in sols])
+
+    # ---- N > 1: the other scaling's job, same K steps (`value_weak` beside a strong `value`, or the other way round)
+    other_line = None
+    if other is not None:
+        o_jobs, o_sizes, _, _, o_worlds, _, _ = other
+        oj = timed_job(o_worlds)
+        o_iters = int(sum(int(s_.admm_iters.sum()) for s_ in oj["sols"]))
+        o_el, o_it = over_ranks(oj["elapsed"], o_iters)
+        other_line = {"scaling": "weak" if strong else "strong", "value": o_it * args.steps / o_el,
+                      "ms_per_step": o_el / max(args.steps, 1) * 1e3, "worlds_total": len(o_jobs), "agents_total": int(sum(o_sizes)),
+                      "admm_iterations_per_step_all_ranks": int(o_it)}
 
     # ---- the PCIe-inclusive DO phase of the batch (csdo.cc:111-148: preprocess + SolverDSQP), outside the timed region, host
     # wall clock around everything, nothing resident: bridge of every world (ONE csdo_preprocess_device_batch call: host
@@ -532,22 +597,14 @@ def main():
                               "the stand-in's coarse paths (worlds the search does not solve) are not collision-free"}
 
     per_rank = None
+    elapsed_max, iters_all = over_ranks(elapsed, iters_step)
     if dist is not None:
-        t = torch.tensor([elapsed, float(iters_step)], dtype=torch.float64, device=dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max = float(tmax[0])
-        iters_all = float(tsum[1])
         mine = torch.tensor([float(sum(w.Na for w in worlds)), float(iters_step), kernel_s / max(args.steps, 1)],
                             dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world_size)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "agents": int(v[0]), "admm_iterations_per_step": int(v[1]),
                      "solve_kernels_ms": float(v[2]) * 1e3} for r, v in enumerate(allr)]
-    else:
-        elapsed_max, iters_all = elapsed, float(iters_step)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -560,8 +617,10 @@ def main():
         dom_avg = group_s[gd] / steps
         achieved = gbytes[gd] / dom_avg / 1e9
         traffic, hbm_frac, valu_frac, pmc_src = (None, None, None, None)
+        from csdotrajectoryplanning_amd import _lib as _csdo_lib
+        lib_hash = _csdo_lib.lib().csdo_source_hash().decode()
         if world_size == 1:
-            traffic, hbm_frac, valu_frac, pmc_src = _newest_pmc(args.workload, elapsed_max / steps * 1e3)
+            traffic, hbm_frac, valu_frac, pmc_src = _newest_pmc(args.workload, elapsed_max / steps * 1e3, lib_hash)
         # what the ADMM iterations cost in the two resources the kernel does use (counts per agent-iteration)
         K_agent = np.concatenate([(w.plane_off[1:] - w.plane_off[:-1]).astype("float64") for w in worlds])
         Nt_agent = np.concatenate([np.full(w.Na, float(w.Nt)) for w in worlds])
@@ -635,7 +694,11 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
+            "kernel_source_hash": lib_hash,
+            "kernel_source_hash_of_tree": _csdo_lib.source_hash_of_tree(),
             "strong_scaling_floor_ms": floor_ms,
+            ("value_weak" if strong else "value_strong"): (other_line["value"] if other_line else None),
+            "other_scaling": other_line,
             "data": "the reference's benchmark instance files (tests/golden/instances = benchmark/map100by100, map50by50, room of "
                     "the reference), no synthetic maps; coarse paths: %d of %d worlds from this repository's own front end "
                     "(stored), %d from the seeded stand-in generator (instances the search does not solve)"

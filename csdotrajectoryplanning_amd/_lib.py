@@ -34,6 +34,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         H = C.c_void_p
         L.csdo_backend_name.restype = C.c_char_p
+        L.csdo_source_hash.restype = C.c_char_p
         L.csdo_dsqp_create.argtypes = [C.POINTER(H), C.c_int]
         L.csdo_dsqp_create_multi.argtypes = [C.POINTER(H), abi.c_int32_p, C.c_int32]
         L.csdo_dsqp_multi_count.argtypes = [H]
@@ -92,3 +93,21 @@ def lib():
         L.csdo_reeds_shepp.restype = C.c_double
         _LIB = L
     return _LIB
+
+
+def source_hash_of_tree():
+    """What csrc/Makefile bakes into the library (csdo_source_hash), recomputed from the tree: the first 16 hex digits of the SHA-256
+    over the device sources in the Makefile's order.  Equal to lib().csdo_source_hash() when the library is a build of this tree."""
+    import hashlib
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    with open(os.path.join(csrc, "Makefile")) as f:
+        mk = f.read()
+    hdrs = re.search(r"^HDRS = (.*)$", mk, re.M).group(1).split()
+    hips = re.search(r"^HIPSRC = (.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for name in sorted(hdrs + hips):          # make's $(sort ...): lexical, duplicates removed
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    h.update(b"\n")                           # (the Makefile appends its XDEFS - empty for the shipped library - and a newline)
+    return h.hexdigest()[:16]

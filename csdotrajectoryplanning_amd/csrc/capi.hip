@@ -151,20 +151,18 @@ static int build_groups(csdo_handle h) {
     ad.rows_lds = rows;
     need[a] = dsqp_lds_bytes(ad.Nt, n_obs, ad.n_planes, key[a].mode, rows != 0, tail);
   }
-  // One residency mode for the 768-thread class of a batch: with F_r in LDS (mode 2) where every such agent fits, else the
-  // lean mode 3 for all of them.  Every (class, mode) pair is a launch group with streams of its own, HIP maps streams onto four
-  // hardware queues, and kernels that share a queue run one after the other: with a fourth group the room set's batch took
-  // 78 ms instead of 61 (58 with GPU_MAX_HW_QUEUES=8) although each of its groups had become faster.
-  {
-    bool any768_lean = false;
-    for (int a = 0; a < Na; ++a) any768_lean |= key[a].block == 768 && (key[a].mode == 3 || h->min_mode >= 3);
-    if (any768_lean)
-      for (int a = 0; a < Na; ++a)
-        if (key[a].block == 768 && key[a].mode != 3) {
-          key[a].mode = 3;
-          need[a] = dsqp_lds_bytes(hbm.agents[a].Nt, hb.worlds[hbm.agents[a].world].n_obs, hbm.agents[a].n_planes, 3, false);
-        }
-  }
+  // The 768-thread class has two residency modes whose solves differ in form (mode 2: pair-split; mode 3: one lane per node) and
+  // therefore in the last bits, so an agent's mode must be a function of THAT AGENT alone (dsqp_agent_class) - results do not
+  // depend on what else is in the batch, how it is chunked or sharded (include/csdo_dsqp.h promises that; round 5 put the whole
+  // class of a batch into mode 3 as soon as one of its agents needed it, which made a long-horizon agent's bits depend on its
+  // neighbours: ADVICE r5).  A batch that mixes the two modes has a launch group more; beyond four groups a group's first launch
+  // shares a hardware queue with an earlier group's (slower, same results).  min_mode >= 3: the testing knob, every such agent lean.
+  if (h->min_mode >= 3)
+    for (int a = 0; a < Na; ++a)
+      if (key[a].block == 768 && key[a].mode != 3) {
+        key[a].mode = 3;
+        need[a] = dsqp_lds_bytes(hbm.agents[a].Nt, hb.worlds[hbm.agents[a].world].n_obs, hbm.agents[a].n_planes, 3, false);
+      }
   h->order.resize(Na);
   for (int a = 0; a < Na; ++a) h->order[a] = a;
   std::stable_sort(h->order.begin(), h->order.end(), [&](int p, int q) {
@@ -287,6 +285,14 @@ static std::vector<int> weighted_cuts(const double* w, int n, int n_blocks) {
   return cuts;
 }
 
+// The multi-device entry points visit every child's device on the CALLER's thread (hipSetDevice is per thread); a caller with
+// work of its own on another device - torch's current device - must find that device current again when the entry returns.
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 // f(k) for every child, each on a host thread of its own (child 0 on the caller's); a thread that cannot be had runs inline, and
 // no exception leaves a joinable thread behind.  Returns the first error.
 template <class F>
@@ -330,6 +336,7 @@ static int for_each_kid(MultiState& M, F&& f) {
 
 static int multi_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_worlds) {
   MultiState& M = *h->multi;
+  const DeviceGuard keep_callers_device;
   if (h->run_pending) return CSDO_EINVAL;
   for (csdo_handle kid : M.kids)
     if (kid->run_pending) return CSDO_EINVAL;
@@ -407,6 +414,7 @@ static int multi_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_wor
 
 static int multi_run_async(csdo_handle h, void* hip_stream) {
   MultiState& M = *h->multi;
+  const DeviceGuard keep_callers_device;
   if (!h->uploaded || h->run_pending) return CSDO_EINVAL;
   int rc = CSDO_OK;
   size_t started = 0;
@@ -428,6 +436,7 @@ static int multi_run_async(csdo_handle h, void* hip_stream) {
 
 static int multi_wait(csdo_handle h) {
   MultiState& M = *h->multi;
+  const DeviceGuard keep_callers_device;
   if (!h->run_pending) return CSDO_EINVAL;
   h->run_pending = false;
   int rc = CSDO_OK;
@@ -443,6 +452,7 @@ static int multi_wait(csdo_handle h) {
 
 static int multi_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
   MultiState& M = *h->multi;
+  const DeviceGuard keep_callers_device;
   if (!h->uploaded || h->run_pending || !results || n_worlds != M.n_worlds) return CSDO_EINVAL;
   const int nk = (int)M.kids.size();
   M.res.assign((size_t)nk, {});
@@ -498,6 +508,11 @@ static int multi_download(csdo_handle h, csdo_result* results, int32_t n_worlds)
 extern "C" {
 
 const char* csdo_backend_name(void) { return "hip-gfx950"; }
+
+#if !defined(CSDO_SOURCE_HASH)
+#define CSDO_SOURCE_HASH "unknown"
+#endif
+const char* csdo_source_hash(void) { return CSDO_SOURCE_HASH; }
 
 int csdo_dsqp_create(csdo_handle* out, int device_ordinal) {
   if (!out) return CSDO_EINVAL;
@@ -591,6 +606,7 @@ int csdo_dsqp_create_multi(csdo_handle* out, const int32_t* devices, int32_t n_d
   }
   h->multi = M;
   h->device = devices[0];
+  const DeviceGuard keep_callers_device;
   int rc = CSDO_OK;
   try {
     for (int k = 0; k < n_devices && rc == CSDO_OK; ++k) {
@@ -629,6 +645,7 @@ csdo_handle csdo_dsqp_multi_child(csdo_handle h, int32_t k) {
 void csdo_dsqp_destroy(csdo_handle h) {
   if (!h) return;
   if (h->multi) {
+    const DeviceGuard keep_callers_device;
     for (csdo_handle kid : h->multi->kids) csdo_dsqp_destroy(kid);
     delete h->multi;
     delete h;

@@ -191,8 +191,8 @@ int csdo_dsqp_last_transfer_seconds(csdo_handle h, double out[5]);
  * workgroups per CU for Nt <= 128 when the working set fits 80 KB, 512 up to Nt = 256, 768 up to 384, 1024 beyond) and LDS residency by
  * working set: 0 = exchange vectors, bounds and the third of the factor that is not in registers in LDS (per agent also
  * the inter-vehicle rows' duals / slacks, where they fit); 1 = that part of the factor read from the workspace instead
- * (512-thread class only; an agent whose obstacle list does not fit beside that layout either runs in the 768-thread class); 2 = the 768-thread class with F_r in LDS (horizons to about 296, and only if every 768-thread
- * agent of the batch fits it); 3 = the 768- and 1024-thread classes: exchange vectors only.  Every group is a set of persistent
+ * (512-thread class only; an agent whose obstacle list does not fit beside that layout either runs in the 768-thread class); 2 = the 768-thread class with F_r in LDS (horizons to about 350
+ * beside the room set's obstacle count; chosen per agent); 3 = the 768- and 1024-thread classes: exchange vectors only.  Every group is a set of persistent
  * workgroups that take its agents off a queue ordered heaviest first, and the groups run concurrently.  `lds_bytes` may
  * be the full 80 / 160 KB of the class: what the agents do not need caches the planes' read-only coefficients.
  * Fills up to `cap` entries, returns the number of groups (or a negative error code).  `seconds` is
@@ -211,8 +211,9 @@ int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t c
 int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_agents);
 /* Testing / tuning knob, from the next upload on (0 restores the automatic choice): 1 keeps the inter-vehicle rows' duals
  * and slacks in the workspace for every agent (the mode stays 0); >= 2 additionally puts the 512-thread class into mode 1.
- * >= 3 additionally keeps the 768-thread class in mode 3.  The 256- and 1024-thread classes have one mode each.  Results do
- * not depend on it, only the speed does. */
+ * >= 3 additionally keeps the 768-thread class in mode 3.  The 256- and 1024-thread classes have one mode each.  Levels 1 and 2
+ * change the speed only (modes 0, 1 and 2 run the same pair-split solve: same bits); level 3 moves agents of the 768-thread class
+ * from the pair-split solve to the one-lane form of mode 3, which sums a node's partials in another order: last bits differ. */
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
 /* The launcher's relative work estimate per agent (the quantity the launch order and the CU shares of the groups come
  * from: horizon, plane count and how much of the initial guess sits in tight spots), in upload order; host code, no GPU
@@ -222,9 +223,10 @@ int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double
  * code, no GPU needed): out[0] threads per workgroup (256 / 512 / 768 / 1024), out[1] LDS residency mode, out[2] whether the
  * inter-vehicle rows' state fits LDS, out[3] capacity of the dense tail of the block cyclic reduction in 6x6 nodes (6, or 8 for
  * horizons of the 512-thread class that lose a level by it), out[4] LDS bytes of that working set (above the per-workgroup limit of
- * 163776: such a world is turned away with CSDO_ELIMIT).  Everything but out[3] only decides the speed; the tail's capacity also
- * decides the elimination order of the last nodes, i.e. last bits - it depends on the agent alone, so results do not depend on how
- * agents are batched, chunked or sharded. */
+ * 163776: such a world is turned away with CSDO_ELIMIT).  Two items decide last bits, the rest only the speed: the tail's capacity
+ * (elimination order of the last nodes) and whether the mode is 3 (one-lane form of the solve) or not (pair-split).  Both are
+ * functions of the agent alone - the launcher never changes an agent's mode because of other agents in the batch -, so results do
+ * not depend on how agents are batched, chunked or sharded (tests/test_gpu_multi.py: a batch that mixes modes 2 and 3). */
 int csdo_dsqp_agent_class(int32_t Nt, int32_t n_obstacles, int32_t n_planes, int64_t out[5]);
 /* Device pointer to the packed solutions of the last run ([sum Na][Nt_stride][6] doubles) for collectives. */
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles);
@@ -351,6 +353,10 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p);
 
 /* Library identification: returns "hip-gfx950". */
 const char* csdo_backend_name(void);
+/* The first 16 hex digits of the SHA-256 over the device sources (csrc/*.h, csrc/*.hip, this header) the library was built from
+ * (csrc/Makefile: CSDO_SOURCE_HASH).  bench.py prints it, scripts/summarize_profiles.py stores it with every counter summary under
+ * profiles/, and bench.py only quotes a summary's counter figures when the two agree: counters of another kernel are not evidence. */
+const char* csdo_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -8,14 +8,63 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#ifdef CSDO_ORACLE_QUAD
+#include <quadmath.h>
+#endif
 
 namespace csdo_oracle {
+
+// The arithmetic type of OSQP's linear algebra (scale_data, the LDL^T, the ADMM updates, the residuals and every test on
+// them).  double = OSQP as the reference links it.  CSDO_ORACLE_QUAD (oracle/Makefile: libcsdo_oracle_q.so): IEEE binary128 -
+// the ARBITER of the chain-parity report (scripts/chain_parity.py): the same algorithm on the same double-precision QP data
+// (assembly, safe boxes and the SQP loop stay in double: the reference defines them so) with 113 instead of 53 bits in the
+// solve, the solution rounded to double once per QP.  CSDO_ORACLE_LONGDOUBLE: x87 extended (64 bits), a faster, weaker arbiter.
+// Constants of the algorithm (sigma, alpha, rho bounds, tolerances) are OSQP's doubles, converted exactly.
+#if defined(CSDO_ORACLE_QUAD)
+typedef __float128 real;
+static inline real r_abs(real a) { return fabsq(a); }
+static inline real r_sqrt(real a) { return sqrtq(a); }
+#elif defined(CSDO_ORACLE_LONGDOUBLE)
+typedef long double real;
+static inline real r_abs(real a) { return fabsl(a); }
+static inline real r_sqrt(real a) { return sqrtl(a); }
+#else
+typedef double real;
+static inline real r_abs(real a) { return std::fabs(a); }
+static inline real r_sqrt(real a) { return std::sqrt(a); }
+#endif
+static inline real r_max(real a, real b) { return std::max(a, b); }
+static inline real r_min(real a, real b) { return std::min(a, b); }
+typedef std::vector<real> rvec;
+
+// Csc with values in the solve's arithmetic
+struct CscR {
+  int m = 0, n = 0;
+  std::vector<int> p, i;
+  rvec x;
+};
+static CscR to_real(const Csc& M) {
+  CscR R;
+  R.m = M.m;
+  R.n = M.n;
+  R.p = M.p;
+  R.i = M.i;
+  R.x.assign(M.x.begin(), M.x.end());
+  return R;
+}
+static rvec to_real(const std::vector<double>& v) { return rvec(v.begin(), v.end()); }
+struct TripletListR {
+  std::vector<int> r, c;
+  rvec v;
+  void add(int row, int col, real val) { r.push_back(row); c.push_back(col); v.push_back(val); }
+};
 
 static thread_local long g_last_factor_nnz = 0;
 long last_factor_nnz() { return g_last_factor_nnz; }
 
-Csc csc_from_triplets(int m, int n, const TripletList& t) {
-  Csc M;
+template <class M_t, class T_t>
+static M_t csc_from_triplets_t(int m, int n, const T_t& t) {
+  M_t M;
   M.m = m;
   M.n = n;
   const size_t nz = t.v.size();
@@ -40,33 +89,35 @@ Csc csc_from_triplets(int m, int n, const TripletList& t) {
   return M;
 }
 
+Csc csc_from_triplets(int m, int n, const TripletList& t) { return csc_from_triplets_t<Csc, TripletList>(m, n, t); }
+
 // ---------------------------------------------------------------------------------------------------------
 // lin_alg.c restated
 // ---------------------------------------------------------------------------------------------------------
-static double vec_norm_inf(const std::vector<double>& v) {
-  double mx = 0.0;
-  for (double a : v) {
-    const double b = std::fabs(a);
+static real vec_norm_inf(const rvec& v) {
+  real mx = 0.0;
+  for (real a : v) {
+    const real b = r_abs(a);
     if (b > mx) mx = b;
   }
   return mx;
 }
-static double vec_scaled_norm_inf(const std::vector<double>& S, const std::vector<double>& v) {
-  double mx = 0.0;
+static real vec_scaled_norm_inf(const rvec& S, const rvec& v) {
+  real mx = 0.0;
   for (size_t k = 0; k < v.size(); ++k) {
-    const double b = std::fabs(S[k] * v[k]);
+    const real b = r_abs(S[k] * v[k]);
     if (b > mx) mx = b;
   }
   return mx;
 }
 // y (+)= A x, column sweep (mat_vec)
-static void mat_vec(const Csc& A, const std::vector<double>& x, std::vector<double>& y, bool plus_eq) {
+static void mat_vec(const CscR& A, const rvec& x, rvec& y, bool plus_eq) {
   if (!plus_eq) std::fill(y.begin(), y.end(), 0.0);
   for (int j = 0; j < A.n; ++j)
     for (int k = A.p[j]; k < A.p[j + 1]; ++k) y[A.i[k]] += A.x[k] * x[j];
 }
 // y (+)= A' x (mat_tpose_vec), optionally skipping the diagonal (used to complete P from its upper triangle)
-static void mat_tpose_vec(const Csc& A, const std::vector<double>& x, std::vector<double>& y, bool plus_eq,
+static void mat_tpose_vec(const CscR& A, const rvec& x, rvec& y, bool plus_eq,
                           bool skip_diag) {
   if (!plus_eq) std::fill(y.begin(), y.end(), 0.0);
   for (int j = 0; j < A.n; ++j)
@@ -76,41 +127,41 @@ static void mat_tpose_vec(const Csc& A, const std::vector<double>& x, std::vecto
       y[j] += A.x[k] * x[i];
     }
 }
-static void inf_norm_cols(const Csc& M, std::vector<double>& E) {
+static void inf_norm_cols(const CscR& M, rvec& E) {
   std::fill(E.begin(), E.end(), 0.0);
   for (int j = 0; j < M.n; ++j)
-    for (int k = M.p[j]; k < M.p[j + 1]; ++k) E[j] = std::max(std::fabs(M.x[k]), E[j]);
+    for (int k = M.p[j]; k < M.p[j + 1]; ++k) E[j] = r_max(r_abs(M.x[k]), E[j]);
 }
-static void inf_norm_rows(const Csc& M, std::vector<double>& E) {
+static void inf_norm_rows(const CscR& M, rvec& E) {
   std::fill(E.begin(), E.end(), 0.0);
   for (int j = 0; j < M.n; ++j)
-    for (int k = M.p[j]; k < M.p[j + 1]; ++k) E[M.i[k]] = std::max(std::fabs(M.x[k]), E[M.i[k]]);
+    for (int k = M.p[j]; k < M.p[j + 1]; ++k) E[M.i[k]] = r_max(r_abs(M.x[k]), E[M.i[k]]);
 }
-static void inf_norm_cols_sym_triu(const Csc& M, std::vector<double>& E) {
+static void inf_norm_cols_sym_triu(const CscR& M, rvec& E) {
   std::fill(E.begin(), E.end(), 0.0);
   for (int j = 0; j < M.n; ++j)
     for (int k = M.p[j]; k < M.p[j + 1]; ++k) {
       const int i = M.i[k];
-      const double a = std::fabs(M.x[k]);
-      E[j] = std::max(a, E[j]);
-      if (i != j) E[i] = std::max(a, E[i]);
+      const real a = r_abs(M.x[k]);
+      E[j] = r_max(a, E[j]);
+      if (i != j) E[i] = r_max(a, E[i]);
     }
 }
-static void premult_diag(Csc& M, const std::vector<double>& d) {
+static void premult_diag(CscR& M, const rvec& d) {
   for (int j = 0; j < M.n; ++j)
     for (int k = M.p[j]; k < M.p[j + 1]; ++k) M.x[k] *= d[M.i[k]];
 }
-static void postmult_diag(Csc& M, const std::vector<double>& d) {
+static void postmult_diag(CscR& M, const rvec& d) {
   for (int j = 0; j < M.n; ++j)
     for (int k = M.p[j]; k < M.p[j + 1]; ++k) M.x[k] *= d[j];
 }
-static void limit_scaling(std::vector<double>& D) {
-  for (double& d : D) {
+static void limit_scaling(rvec& D) {
+  for (real& d : D) {
     d = d < MIN_SCALING ? 1.0 : d;
     d = d > MAX_SCALING ? MAX_SCALING : d;
   }
 }
-static double limit_scaling1(double d) {
+static real limit_scaling1(real d) {
   d = d < MIN_SCALING ? 1.0 : d;
   d = d > MAX_SCALING ? MAX_SCALING : d;
   return d;
@@ -122,12 +173,12 @@ static double limit_scaling1(double d) {
 struct Ldl {
   int n = 0;
   std::vector<int> etree, Lnz, Lp, Li;
-  std::vector<double> Lx, D, Dinv;
+  rvec Lx, D, Dinv;
   // work
   std::vector<int> ymark, yidx, ebuf, lnext;
-  std::vector<double> yvals;
+  rvec yvals;
 
-  bool symbolic(const Csc& K) {
+  bool symbolic(const CscR& K) {
     n = K.n;
     etree.assign(n, -1);
     Lnz.assign(n, 0);
@@ -160,7 +211,7 @@ struct Ldl {
   }
 
   // returns number of positive pivots, or -1 on a zero pivot
-  int numeric(const Csc& K) {
+  int numeric(const CscR& K) {
     int positive = 0;
     for (int i = 0; i < n; ++i) {
       ymark[i] = 0;
@@ -195,7 +246,7 @@ struct Ldl {
       for (int q = nnzY - 1; q >= 0; --q) {
         const int c = yidx[q];
         const int tmp = lnext[c];
-        const double yc = yvals[c];
+        const real yc = yvals[c];
         for (int j = Lp[c]; j < tmp; ++j) yvals[Li[j]] -= Lx[j] * yc;
         Li[tmp] = k;
         Lx[tmp] = yc * Dinv[c];
@@ -211,14 +262,14 @@ struct Ldl {
     return positive;
   }
 
-  void solve(std::vector<double>& x) const {
+  void solve(rvec& x) const {
     for (int i = 0; i < n; ++i) {
-      const double v = x[i];
+      const real v = x[i];
       for (int j = Lp[i]; j < Lp[i + 1]; ++j) x[Li[j]] -= Lx[j] * v;
     }
     for (int i = 0; i < n; ++i) x[i] *= Dinv[i];
     for (int i = n - 1; i >= 0; --i) {
-      double v = x[i];
+      real v = x[i];
       for (int j = Lp[i]; j < Lp[i + 1]; ++j) v -= Lx[j] * x[Li[j]];
       x[i] = v;
     }
@@ -228,14 +279,14 @@ struct Ldl {
 // KKT = [P + sigma I, A'; A, -diag(1/rho)] (kkt.c form_KKT, format 0), symmetrically permuted, upper triangle.
 struct Kkt {
   int n = 0, m = 0;
-  Csc K;                      // permuted upper triangle
+  CscR K;                      // permuted upper triangle
   std::vector<int> perm;      // perm[k] = original index placed at position k
   std::vector<int> iperm;
   std::vector<int> rho_pos;   // position in K.x of the -1/rho_i diagonal entry
   Ldl ldl;
-  std::vector<double> bp;
+  rvec bp;
 
-  void build(const Csc& P, const Csc& A, double sigma, const std::vector<double>& rho_inv,
+  void build(const CscR& P, const CscR& A, real sigma, const rvec& rho_inv,
              const std::vector<int>* var_order) {
     n = P.n;
     m = A.m;
@@ -247,9 +298,9 @@ struct Kkt {
     for (int j = 0; j < n; ++j) perm[m + j] = var_order ? (*var_order)[j] : j;
     for (int k = 0; k < N; ++k) iperm[perm[k]] = k;
 
-    TripletList T;
+    TripletListR T;
     std::vector<char> has_diag(n, 0);
-    auto put = [&](int r, int c, double v) {
+    auto put = [&](int r, int c, real v) {
       int a = iperm[r], b = iperm[c];
       if (a > b) std::swap(a, b);
       T.add(a, b, v);
@@ -269,7 +320,7 @@ struct Kkt {
     for (int j = 0; j < n; ++j)
       for (int k = A.p[j]; k < A.p[j + 1]; ++k) put(j, n + A.i[k], A.x[k]);
     for (int i = 0; i < m; ++i) put(n + i, n + i, -rho_inv[i]);
-    K = csc_from_triplets(N, N, T);
+    K = csc_from_triplets_t<CscR, TripletListR>(N, N, T);
     rho_pos.assign(m, -1);
     for (int i = 0; i < m; ++i) {
       const int c = iperm[n + i];
@@ -284,11 +335,11 @@ struct Kkt {
     g_last_factor_nnz = ldl.Lp[N];
   }
   bool factor() { return ldl.numeric(K) >= 0; }
-  void update_rho(const std::vector<double>& rho_inv) {
+  void update_rho(const rvec& rho_inv) {
     for (int i = 0; i < m; ++i) K.x[rho_pos[i]] = -rho_inv[i];
   }
   // LDLSolve of qdldl_interface.c: permute, solve, un-permute
-  void solve(std::vector<double>& b) {
+  void solve(rvec& b) {
     const int N = n + m;
     for (int k = 0; k < N; ++k) bp[k] = b[perm[k]];
     ldl.solve(bp);
@@ -301,17 +352,18 @@ struct Kkt {
 // ---------------------------------------------------------------------------------------------------------
 struct Work {
   int n, m;
-  Csc P, A;  // scaled copies
-  std::vector<double> q, l, u;
-  std::vector<double> D, Dinv, E, Einv;
-  double c = 1.0, cinv = 1.0;
-  std::vector<double> rho_vec, rho_inv_vec;
+  CscR P, A;  // scaled copies
+  rvec q, l, u;
+  rvec D, Dinv, E, Einv;
+  real c = 1.0, cinv = 1.0;
+  rvec rho_vec, rho_inv_vec;
   std::vector<int> constr_type;
-  double rho;
-  std::vector<double> x, y, z, xz_tilde, x_prev, z_prev, Ax, Px, Aty, delta_y, Atdelta_y, delta_x, Pdelta_x,
+  real rho;
+  rvec x, y, z, xz_tilde, x_prev, z_prev, Ax, Px, Aty, delta_y, Atdelta_y, delta_x, Pdelta_x,
       Adelta_x;
   Kkt kkt;
   Info info;
+  real pri_res = 0, dua_res = 0;  // info.pri_res / info.dua_res in the solve's arithmetic (the tests read these)
 };
 
 // scaling.c scale_data
@@ -322,17 +374,17 @@ static void scale_data(Work& w, int passes) {
   w.Dinv.assign(n, 1.0);
   w.E.assign(m, 1.0);
   w.Einv.assign(m, 1.0);
-  std::vector<double> Dt(n), DtA(n), Et(m);
+  rvec Dt(n), DtA(n), Et(m);
   for (int it = 0; it < passes; ++it) {
     // norms of the KKT columns [P;A] and [A';0]
     inf_norm_cols_sym_triu(w.P, Dt);
     inf_norm_cols(w.A, DtA);
-    for (int j = 0; j < n; ++j) Dt[j] = std::max(Dt[j], DtA[j]);
+    for (int j = 0; j < n; ++j) Dt[j] = r_max(Dt[j], DtA[j]);
     inf_norm_rows(w.A, Et);
     limit_scaling(Dt);
     limit_scaling(Et);
-    for (double& d : Dt) d = 1.0 / std::sqrt(d);
-    for (double& e : Et) e = 1.0 / std::sqrt(e);
+    for (real& d : Dt) d = 1.0 / r_sqrt(d);
+    for (real& e : Et) e = 1.0 / r_sqrt(e);
     premult_diag(w.P, Dt);
     postmult_diag(w.P, Dt);
     premult_diag(w.A, Et);
@@ -342,15 +394,15 @@ static void scale_data(Work& w, int passes) {
     for (int i = 0; i < m; ++i) w.E[i] = w.E[i] * Et[i];
     // cost normalisation
     inf_norm_cols_sym_triu(w.P, Dt);
-    double c_temp = 0.0;
+    real c_temp = 0.0;
     for (int j = 0; j < n; ++j) c_temp += Dt[j];
-    c_temp /= (double)n;
-    double inf_norm_q = limit_scaling1(vec_norm_inf(w.q));
-    c_temp = std::max(c_temp, inf_norm_q);
+    c_temp /= (real)n;
+    real inf_norm_q = limit_scaling1(vec_norm_inf(w.q));
+    c_temp = r_max(c_temp, inf_norm_q);
     c_temp = limit_scaling1(c_temp);
     c_temp = 1.0 / c_temp;
-    for (double& v : w.P.x) v *= c_temp;
-    for (double& v : w.q) v *= c_temp;
+    for (real& v : w.P.x) v *= c_temp;
+    for (real& v : w.q) v *= c_temp;
     w.c *= c_temp;
   }
   w.cinv = 1.0 / w.c;
@@ -362,7 +414,7 @@ static void scale_data(Work& w, int passes) {
 
 // auxil.c set_rho_vec
 static void set_rho_vec(Work& w) {
-  w.rho = std::min(std::max(w.rho, RHO_MIN), RHO_MAX);
+  w.rho = r_min(r_max(w.rho, RHO_MIN), RHO_MAX);
   for (int i = 0; i < w.m; ++i) {
     if (w.l[i] < -OSQP_INFTY * MIN_SCALING && w.u[i] > OSQP_INFTY * MIN_SCALING) {
       w.constr_type[i] = -1;
@@ -379,12 +431,12 @@ static void set_rho_vec(Work& w) {
 }
 
 // auxil.c compute_pri_res / compute_dua_res (leave Ax-z in z_prev and Px+q+A'y in x_prev, as upstream does)
-static double compute_pri_res(Work& w) {
+static real compute_pri_res(Work& w) {
   mat_vec(w.A, w.x, w.Ax, false);
   for (int i = 0; i < w.m; ++i) w.z_prev[i] = w.Ax[i] - w.z[i];
   return vec_scaled_norm_inf(w.Einv, w.z_prev);
 }
-static double compute_dua_res(Work& w) {
+static real compute_dua_res(Work& w) {
   w.x_prev = w.q;
   mat_vec(w.P, w.x, w.Px, false);
   mat_tpose_vec(w.P, w.x, w.Px, true, true);
@@ -397,18 +449,18 @@ static double compute_dua_res(Work& w) {
 }
 static void update_info(Work& w, int iter) {
   w.info.iter = iter;
-  w.info.pri_res = (w.m == 0) ? 0.0 : compute_pri_res(w);
-  w.info.dua_res = compute_dua_res(w);
+  w.pri_res = (w.m == 0) ? 0.0 : compute_pri_res(w);
+  w.dua_res = compute_dua_res(w);
 }
-static double compute_pri_tol(const Work& w, double eps_abs, double eps_rel) {
-  double mx = vec_scaled_norm_inf(w.Einv, w.z);
-  mx = std::max(mx, vec_scaled_norm_inf(w.Einv, w.Ax));
+static real compute_pri_tol(const Work& w, real eps_abs, real eps_rel) {
+  real mx = vec_scaled_norm_inf(w.Einv, w.z);
+  mx = r_max(mx, vec_scaled_norm_inf(w.Einv, w.Ax));
   return eps_abs + eps_rel * mx;
 }
-static double compute_dua_tol(const Work& w, double eps_abs, double eps_rel) {
-  double mx = vec_scaled_norm_inf(w.Dinv, w.q);
-  mx = std::max(mx, vec_scaled_norm_inf(w.Dinv, w.Aty));
-  mx = std::max(mx, vec_scaled_norm_inf(w.Dinv, w.Px));
+static real compute_dua_tol(const Work& w, real eps_abs, real eps_rel) {
+  real mx = vec_scaled_norm_inf(w.Dinv, w.q);
+  mx = r_max(mx, vec_scaled_norm_inf(w.Dinv, w.Aty));
+  mx = r_max(mx, vec_scaled_norm_inf(w.Dinv, w.Px));
   mx *= w.cinv;
   return eps_abs + eps_rel * mx;
 }
@@ -416,23 +468,23 @@ static double compute_dua_tol(const Work& w, double eps_abs, double eps_rel) {
 // auxil.c is_primal_infeasible.  NOTE (reference quirk): the reference passes a true -infinity lower bound
 // for inter-vehicle rows (sqp/dsqp_solver.cc:1121-1123); l_i * min(dy_i,0) is then (-inf)*0 = NaN and the
 // certificate test below is false for every agent that has inter-vehicle rows.  IEEE semantics reproduce that.
-static bool is_primal_infeasible(Work& w, double eps_prim_inf) {
+static bool is_primal_infeasible(Work& w, real eps_prim_inf) {
   for (int i = 0; i < w.m; ++i) {
     if (w.u[i] > OSQP_INFTY * MIN_SCALING) {
       if (w.l[i] < -OSQP_INFTY * MIN_SCALING)
         w.delta_y[i] = 0.0;
       else
-        w.delta_y[i] = std::min(w.delta_y[i], 0.0);
+        w.delta_y[i] = r_min(w.delta_y[i], 0.0);
     } else if (w.l[i] < -OSQP_INFTY * MIN_SCALING) {
-      w.delta_y[i] = std::max(w.delta_y[i], 0.0);
+      w.delta_y[i] = r_max(w.delta_y[i], 0.0);
     }
   }
   for (int i = 0; i < w.m; ++i) w.Adelta_x[i] = w.E[i] * w.delta_y[i];
-  const double norm_dy = vec_norm_inf(w.Adelta_x);
+  const real norm_dy = vec_norm_inf(w.Adelta_x);
   if (norm_dy > eps_prim_inf) {
-    double lhs = 0.0;
+    real lhs = 0.0;
     for (int i = 0; i < w.m; ++i)
-      lhs += w.u[i] * std::max(w.delta_y[i], 0.0) + w.l[i] * std::min(w.delta_y[i], 0.0);
+      lhs += w.u[i] * r_max(w.delta_y[i], 0.0) + w.l[i] * r_min(w.delta_y[i], 0.0);
     if (lhs < -eps_prim_inf * norm_dy) {
       mat_tpose_vec(w.A, w.delta_y, w.Atdelta_y, false, false);
       for (int j = 0; j < w.n; ++j) w.Atdelta_y[j] = w.Dinv[j] * w.Atdelta_y[j];
@@ -443,11 +495,11 @@ static bool is_primal_infeasible(Work& w, double eps_prim_inf) {
 }
 
 // auxil.c is_dual_infeasible
-static bool is_dual_infeasible(Work& w, double eps_dual_inf) {
-  const double norm_dx = vec_scaled_norm_inf(w.D, w.delta_x);
-  const double cost_scaling = w.c;
+static bool is_dual_infeasible(Work& w, real eps_dual_inf) {
+  const real norm_dx = vec_scaled_norm_inf(w.D, w.delta_x);
+  const real cost_scaling = w.c;
   if (norm_dx > eps_dual_inf) {
-    double qdx = 0.0;
+    real qdx = 0.0;
     for (int j = 0; j < w.n; ++j) qdx += w.q[j] * w.delta_x[j];
     if (qdx < -cost_scaling * eps_dual_inf * norm_dx) {
       mat_vec(w.P, w.delta_x, w.Pdelta_x, false);
@@ -470,9 +522,9 @@ static bool is_dual_infeasible(Work& w, double eps_dual_inf) {
 
 // auxil.c check_termination
 static bool check_termination(Work& w, const Settings& st, bool approximate) {
-  double eps_abs = st.eps_abs, eps_rel = st.eps_rel, eps_pinf = st.eps_prim_inf, eps_dinf = st.eps_dual_inf;
+  real eps_abs = st.eps_abs, eps_rel = st.eps_rel, eps_pinf = st.eps_prim_inf, eps_dinf = st.eps_dual_inf;
   bool prim_res_check = false, dual_res_check = false, prim_inf_check = false, dual_inf_check = false;
-  if (w.info.pri_res > OSQP_INFTY || w.info.dua_res > OSQP_INFTY) {
+  if (w.pri_res > OSQP_INFTY || w.dua_res > OSQP_INFTY) {
     w.info.status = NON_CVX;
     return true;
   }
@@ -485,14 +537,14 @@ static bool check_termination(Work& w, const Settings& st, bool approximate) {
   if (w.m == 0) {
     prim_res_check = true;
   } else {
-    const double eps_prim = compute_pri_tol(w, eps_abs, eps_rel);
-    if (w.info.pri_res < eps_prim)
+    const real eps_prim = compute_pri_tol(w, eps_abs, eps_rel);
+    if (w.pri_res < eps_prim)
       prim_res_check = true;
     else
       prim_inf_check = is_primal_infeasible(w, eps_pinf);
   }
-  const double eps_dual = compute_dua_tol(w, eps_abs, eps_rel);
-  if (w.info.dua_res < eps_dual)
+  const real eps_dual = compute_dua_tol(w, eps_abs, eps_rel);
+  if (w.dua_res < eps_dual)
     dual_res_check = true;
   else
     dual_inf_check = is_dual_infeasible(w, eps_dinf);
@@ -511,17 +563,17 @@ static bool check_termination(Work& w, const Settings& st, bool approximate) {
 }
 
 // auxil.c compute_rho_estimate (uses the scaled residual vectors left in z_prev / x_prev by update_info)
-static double compute_rho_estimate(const Work& w, const Settings&) {
-  double pri_res = vec_norm_inf(w.z_prev);
-  double dua_res = vec_norm_inf(w.x_prev);
-  double pri_norm = std::max(vec_norm_inf(w.z), vec_norm_inf(w.Ax));
+static real compute_rho_estimate(const Work& w, const Settings&) {
+  real pri_res = vec_norm_inf(w.z_prev);
+  real dua_res = vec_norm_inf(w.x_prev);
+  real pri_norm = r_max(vec_norm_inf(w.z), vec_norm_inf(w.Ax));
   pri_res /= (pri_norm + 1e-10);
-  double dua_norm = vec_norm_inf(w.q);
-  dua_norm = std::max(dua_norm, vec_norm_inf(w.Aty));
-  dua_norm = std::max(dua_norm, vec_norm_inf(w.Px));
+  real dua_norm = vec_norm_inf(w.q);
+  dua_norm = r_max(dua_norm, vec_norm_inf(w.Aty));
+  dua_norm = r_max(dua_norm, vec_norm_inf(w.Px));
   dua_res /= (dua_norm + 1e-10);
-  double est = w.rho * std::sqrt(pri_res / (dua_res + 1e-10));
-  est = std::min(std::max(est, RHO_MIN), RHO_MAX);
+  real est = w.rho * r_sqrt(pri_res / (dua_res + 1e-10));
+  est = r_min(r_max(est, RHO_MIN), RHO_MAX);
   return est;
 }
 
@@ -533,11 +585,11 @@ Info osqp_solve_restated(const Csc& P_triu, const std::vector<double>& q, const 
   const int n = w.n = P_triu.n;
   const int m = w.m = A.m;
   // ---- osqp_setup ----
-  w.P = P_triu;
-  w.A = A;
-  w.q = q;
-  w.l = l;
-  w.u = u;
+  w.P = to_real(P_triu);
+  w.A = to_real(A);
+  w.q = to_real(q);
+  w.l = to_real(l);
+  w.u = to_real(u);
   w.rho = st.rho;
   w.rho_vec.assign(m, 0.0);
   w.rho_inv_vec.assign(m, 0.0);
@@ -572,7 +624,7 @@ Info osqp_solve_restated(const Csc& P_triu, const std::vector<double>& q, const 
   w.info.status = UNSOLVED;
 
   // ---- osqp_warm_start_x: x <- Dinv x0, z <- A x, y stays 0 ----
-  for (int j = 0; j < n; ++j) w.x[j] = w.Dinv[j] * x_warm[j];
+  for (int j = 0; j < n; ++j) w.x[j] = w.Dinv[j] * real(x_warm[j]);
   mat_vec(w.A, w.x, w.z, false);
 
   // ---- osqp_solve ----
@@ -585,7 +637,7 @@ Info osqp_solve_restated(const Csc& P_triu, const std::vector<double>& q, const 
     for (int j = 0; j < n; ++j) w.xz_tilde[j] = st.sigma * w.x_prev[j] - w.q[j];
     for (int i = 0; i < m; ++i) w.xz_tilde[n + i] = w.z_prev[i] - w.rho_inv_vec[i] * w.y[i];
     {
-      std::vector<double> sol = w.xz_tilde;
+      rvec sol = w.xz_tilde;
       w.kkt.solve(sol);
       for (int j = 0; j < n; ++j) w.xz_tilde[j] = sol[j];
       for (int i = 0; i < m; ++i) w.xz_tilde[n + i] += w.rho_inv_vec[i] * sol[n + i];
@@ -596,7 +648,7 @@ Info osqp_solve_restated(const Csc& P_triu, const std::vector<double>& q, const 
     // update_z + project
     for (int i = 0; i < m; ++i)
       w.z[i] = st.alpha * w.xz_tilde[n + i] + (1.0 - st.alpha) * w.z_prev[i] + w.rho_inv_vec[i] * w.y[i];
-    for (int i = 0; i < m; ++i) w.z[i] = std::min(std::max(w.z[i], w.l[i]), w.u[i]);
+    for (int i = 0; i < m; ++i) w.z[i] = r_min(r_max(w.z[i], w.l[i]), w.u[i]);
     // update_y
     for (int i = 0; i < m; ++i) {
       w.delta_y[i] = w.rho_vec[i] * (st.alpha * w.xz_tilde[n + i] + (1.0 - st.alpha) * w.z_prev[i] - w.z[i]);
@@ -607,18 +659,18 @@ Info osqp_solve_restated(const Csc& P_triu, const std::vector<double>& q, const 
     if (can_check) {
       update_info(w, iter);
       if (trace) {
-        trace->pri_res_hist.push_back(w.info.pri_res);
-        trace->dua_res_hist.push_back(w.info.dua_res);
-        trace->rho_hist.push_back(w.rho);
+        trace->pri_res_hist.push_back((double)w.pri_res);
+        trace->dua_res_hist.push_back((double)w.dua_res);
+        trace->rho_hist.push_back((double)w.rho);
       }
       if (check_termination(w, st, false)) break;
     }
     if (st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0)) {
       if (!can_check) update_info(w, iter);
-      const double rho_new = compute_rho_estimate(w, st);
+      const real rho_new = compute_rho_estimate(w, st);
       if (rho_new > w.rho * st.adaptive_rho_tolerance || rho_new < w.rho / st.adaptive_rho_tolerance) {
         // osqp_update_rho
-        w.rho = std::min(std::max(rho_new, RHO_MIN), RHO_MAX);
+        w.rho = r_min(r_max(rho_new, RHO_MIN), RHO_MAX);
         for (int i = 0; i < m; ++i) {
           if (w.constr_type[i] == 0) {
             w.rho_vec[i] = w.rho;
@@ -645,26 +697,28 @@ Info osqp_solve_restated(const Csc& P_triu, const std::vector<double>& q, const 
   }
   if (iter > st.max_iter) iter = st.max_iter;
   w.info.iter = iter;
-  w.info.rho_final = w.rho;
+  w.info.rho_final = (double)w.rho;
+  w.info.pri_res = (double)w.pri_res;
+  w.info.dua_res = (double)w.dua_res;
 
   // store_solution / unscale_solution
   x_out.assign(n, std::numeric_limits<double>::quiet_NaN());
   if (y_out) y_out->assign(m, std::numeric_limits<double>::quiet_NaN());
   if (has_solution(w.info.status)) {
-    for (int j = 0; j < n; ++j) x_out[j] = w.D[j] * w.x[j];
+    for (int j = 0; j < n; ++j) x_out[j] = (double)(w.D[j] * w.x[j]);
     if (y_out)
-      for (int i = 0; i < m; ++i) (*y_out)[i] = w.cinv * (w.E[i] * w.y[i]);
+      for (int i = 0; i < m; ++i) (*y_out)[i] = (double)(w.cinv * (w.E[i] * w.y[i]));
   }
   if (trace) {
-    trace->D = w.D;
-    trace->E = w.E;
-    trace->c = w.c;
-    trace->l_s = w.l;
-    trace->u_s = w.u;
-    trace->rho_vec = w.rho_vec;
-    trace->x_scaled = w.x;
-    trace->y_scaled = w.y;
-    trace->z_scaled = w.z;
+    trace->D.assign(w.D.begin(), w.D.end());
+    trace->E.assign(w.E.begin(), w.E.end());
+    trace->c = (double)w.c;
+    trace->l_s.assign(w.l.begin(), w.l.end());
+    trace->u_s.assign(w.u.begin(), w.u.end());
+    trace->rho_vec.assign(w.rho_vec.begin(), w.rho_vec.end());
+    trace->x_scaled.assign(w.x.begin(), w.x.end());
+    trace->y_scaled.assign(w.y.begin(), w.y.end());
+    trace->z_scaled.assign(w.z.begin(), w.z.end());
   }
   return w.info;
 }

@@ -1,0 +1,77 @@
+"""Runs every solver of the chain-parity report on a whole workload and caches the per-agent results (solutions, corridors, counts) under
+oracle/_cache/ (git-ignored): the binary128 arbiter takes minutes per workload, the reports that read it (scripts/chain_parity.py,
+tests/golden/make_arbiter_fixture.py) seconds.   python scripts/arbiter_run.py --workload map100 [--solvers q,qxm,oracle,...]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CACHE = os.path.join(ROOT, "oracle", "_cache")
+ALL = ("product", "oracle", "oracle_fma", "oracle_xm", "oracle_ld", "oracle_q", "oracle_qxm")
+
+
+def run(name, worlds, threads):
+    from tests import emu_lib, oracle_lib
+    if name == "product":
+        return emu_lib.solve_batch(worlds, 0, threads)
+    if name.startswith("product:"):                       # product:<flags>  - the lane-serial build with csdo_qp_parm flags set
+        return emu_lib.solve_batch([with_flags(w, int(name.split(":")[1])) for w in worlds], 0, threads)
+    if name == "oracle":
+        return oracle_lib.solve_batch(worlds, threads)
+    return oracle_lib.solve_batch_variant(worlds, name.split("_", 1)[1], threads)
+
+
+def with_flags(world, flags):
+    from csdotrajectoryplanning_amd.abi import QpParm
+    from csdotrajectoryplanning_amd.problem import World
+    p = QpParm.from_buffer_copy(bytes(world.parm))
+    p.solve_flags = flags
+    return World(world.x0_bar, world.plane_off, world.planes, world.dimx, world.dimy, world.obstacles, world.veh, p)
+
+
+def pack(sols):
+    return {"solutions": np.concatenate([s.solutions.reshape(-1) for s in sols]),
+            "corridors": np.concatenate([s.corridors.reshape(-1) for s in sols]),
+            "sqp_iters": np.concatenate([s.sqp_iters for s in sols]), "admm_iters": np.concatenate([s.admm_iters for s in sols]),
+            "last_status": np.concatenate([s.last_status for s in sols]),
+            "Na": np.array([s.solutions.shape[0] for s in sols]), "Nt": np.array([s.solutions.shape[1] for s in sols])}
+
+
+def cache_path(workload, name):
+    return os.path.join(CACHE, "%s_%s.npz" % (workload, name.replace(":", "_")))
+
+
+def load(workload, name):
+    """Per-agent arrays of one solver on one workload: list of (solutions [Nt, 6], corridors [Nt, 8]) per agent + count arrays."""
+    z = np.load(cache_path(workload, name))
+    return z
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", required=True)
+    ap.add_argument("--solvers", default=",".join(ALL))
+    ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 8, 32))
+    ap.add_argument("--force", action="store_true")
+    args = ap.parse_args()
+    from csdotrajectoryplanning_amd import workloads
+    os.makedirs(CACHE, exist_ok=True)
+    worlds = None
+    for name in args.solvers.split(","):
+        path = cache_path(args.workload, name)
+        if os.path.exists(path) and not args.force:
+            continue
+        if worlds is None:
+            worlds = [w for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(args.workload, None), args.threads)]
+        t = time.time()
+        sols = run(name, worlds, args.threads)
+        np.savez_compressed(path, **pack(sols))
+        print("%s %s: %d agents, %.1f s" % (args.workload, name, sum(w.Na for w in worlds), time.time() - t), flush=True)
+
+
+if __name__ == "__main__":
+    main()

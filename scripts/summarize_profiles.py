@@ -24,6 +24,14 @@ def find(pattern):
 
 
 summary = {"workload": wl}
+# which kernel the counters belong to: the bench line of the traced run carries the library's csdo_source_hash() (bench.py quotes a
+# summary only when it equals the running library's)
+try:
+    with open(os.path.join(base, "trace.log")) as fh:
+        line = [l for l in fh.read().splitlines() if l.startswith("{")][-1]
+    summary["kernel_source_hash"] = json.loads(line).get("kernel_source_hash")
+except Exception as e:
+    print("no bench line in trace.log (%s): the summary carries no kernel_source_hash and bench.py will not quote it" % e)
 for f in find("trace/**/*kernel_stats.csv"):
     shutil.copy(f, os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, wl)))
     with open(f) as fh:

@@ -63,3 +63,10 @@ def test_no_cpu_fallback_without_a_device():
     from csdotrajectoryplanning_amd.solver import DsqpHandle
     with pytest.raises(_lib.CsdoError):
         DsqpHandle(0)
+
+
+def test_library_is_a_build_of_this_tree():
+    """csdo_source_hash() (baked in by csrc/Makefile) equals the hash of the device sources in the tree: the counter summaries under
+    profiles/ are keyed by it (bench.py: _newest_pmc)."""
+    from csdotrajectoryplanning_amd import _lib
+    assert _lib.lib().csdo_source_hash().decode() == _lib.source_hash_of_tree()

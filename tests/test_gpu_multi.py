@@ -108,3 +108,41 @@ def test_a_world_that_does_not_fit_is_named_in_the_callers_indices(gpu_handle, v
         assert _same(h.solve(small), gpu_handle.solve(small))      # the handle is usable afterwards
     finally:
         h.close()
+
+
+def test_mixed_768_batch_is_batch_chunk_and_shard_independent(gpu_handle, veh_parm):
+    """the 768-thread class has two residency modes whose solves differ in form - 2: pair-split, 3: one lane per
+    node - and hence in last bits.  Round 5 put EVERY 768-thread agent of a batch into mode 3 as soon as one of them needed it, so a
+    long-horizon agent's bits depended on its neighbours (and on which shard it landed in).  The mode is now the agent's own
+    (dsqp_agent_class): a batch that mixes mode-2 agents (a room world's 257..343-step horizons, a 271-step line), a mode-3 agent by
+    horizon (379 steps) and mode-3 agents by obstacle count (5000 obstacles beside 91 steps) returns, world for world, the bits of
+    each world solved alone, and the same bits through create_multi with two and three children."""
+    from csdotrajectoryplanning_amd import workloads
+    from csdotrajectoryplanning_amd.problem import World
+    from csdotrajectoryplanning_amd.solver import DsqpHandle
+    veh, parm = veh_parm
+    room = [workloads.build_job(j)[0] for j in workloads.workload_jobs("room50", 12)]
+    room = [w for w in room if w.Nt > 256][:1]
+    assert room, "the room set has worlds with horizons beyond 256"
+    line2 = helpers.straight_line_world(veh, parm, Na=2, L=90, dim=600.0, spacing=3.5)      # Nt = 271: mode 2
+    line3 = helpers.straight_line_world(veh, parm, Na=2, L=126, dim=600.0, spacing=3.5)     # Nt = 379: mode 3 by horizon
+    short, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    rng = np.random.default_rng(2)
+    far = np.column_stack([rng.uniform(300, 400, 5000), rng.uniform(300, 400, 5000), np.full(5000, 0.5)])
+    heavy = World(short.x0_bar, short.plane_off, short.planes, 500.0, 500.0, np.vstack([short.obstacles, far]), veh, short.parm)
+    batch = [line2, heavy] + room + [line3]
+    got = gpu_handle.solve_batch(batch)
+    kinds = {(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()}
+    assert {(768, 2), (768, 3)} <= kinds, kinds
+    for w, b in zip(batch, got):
+        assert _same(gpu_handle.solve(w), b)
+    # a batch WITHOUT the lean agents: the mode-2 worlds keep their bits
+    sub = gpu_handle.solve_batch([line2] + room)
+    assert {(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()} >= {(768, 2)}
+    assert _same(sub[0], got[0]) and _same(sub[1], got[2])
+    for n_dev in (2, 3):
+        h = DsqpHandle(devices=[0] * n_dev)
+        try:
+            assert all(_same(g, r) for g, r in zip(h.solve_batch(batch), got))
+        finally:
+            h.close()

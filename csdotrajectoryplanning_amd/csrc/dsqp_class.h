@@ -33,16 +33,7 @@ inline int dsqp_tail_stride(int nt, int tail_nodes) {
   return h;
 }
 
-#if !defined(CSDO_TAIL_BIG)
-#define CSDO_TAIL_BIG 1   // 0: six nodes for every agent; 1: eight where that saves a level (horizons 193 .. 256)
-#endif
-#if CSDO_TAIL_BIG >= 2
-// (twelve nodes were measured in round 5 - slower: the dense inversion of a 66 x 66 system costs a short agent more than the level
-//  gives back - with tail phases written for ONE wave: `wl < 63 && r < n_tail` on the last 64 lanes covers 63 rows, a twelve-node
-//  tail has 72.  Not a build option until the tail phases span more than one wave.)
-#error "CSDO_TAIL_BIG >= 2 (twelve-node tail) is not supported: the tail phases cover at most 63 rows (one wave)"
-#endif
-
+// (CSDO_TAIL_BIG: dsqp_layout.h)
 // returns the workgroup size; sets the residency mode, whether the rows' state fits LDS, and the tail's capacity
 inline int dsqp_agent_class(int nt, int n_obs, int n_planes, int* mode, int* rows_lds, int* tail_nodes) {
   // workgroup size: two specialised lanes per timestep (Nt <= 128: 256 threads, <= 256: 512 threads, <= 512: 1024

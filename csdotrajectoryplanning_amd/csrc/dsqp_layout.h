@@ -10,6 +10,14 @@ constexpr int TAIL_NODES = 6, TAIL_N = 6 * TAIL_NODES;
 // The 512-thread class may keep a larger tail where that saves a level of the reduction and the agent's LDS has room for the
 // inverse (AgentDesc::tail_nodes = 8 or 12, dsqp_class.h): its kernels read the tail's size at run time (BIGT below).
 constexpr int TAIL_NODES_BIG = 12, TAIL_N_BIG = 6 * TAIL_NODES_BIG;
+#if !defined(CSDO_TAIL_BIG)
+#define CSDO_TAIL_BIG 1   // 0: six nodes for every agent; 1: eight where that saves a level (horizons 193 .. 256); 2: also a FOLDED tail of
+                          // twelve (horizons 97 .. 192 of the 512-thread class): six nodes inverted densely, the inverse expanded by the last level's factors
+#endif
+// (2, round 6: measured, not shipped - per iteration a folded agent saves a level in both sweeps, 1.6 k cycles of 14 k, and gives half
+//  of it back waiting for the 72 x 72 tail product, whose 72 LDS reads per lane on four row waves saturate the LDS pipe; the expansion
+//  costs 20 k cycles per SQP iteration and the larger inverse takes the LDS that cached the planes' coefficients: map100 53.2 -> 54.0 ms,
+//  one instance alone 8.32 -> 8.19 ms; profiles/r06_phase_profile_map100_folded_tail.txt)
 
 #if !defined(CSDO_SINV_LDS)
 #define CSDO_SINV_LDS 1   // 1: the pivot inverse of a node (21 doubles, read once per iteration in the w pass) sits in LDS; 0: in the workspace

@@ -165,12 +165,22 @@ struct FactorProf {};
 template <int ROLE, int MODE, bool BIGT>
 CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t rcap_in, const int32_t* tstart_in,
                               const int Nt_in, const int h_tail_in, const int n_tail_in, const double sigma_in,
-                              const double rho_in, const FactorProf fprof) {
+                              const double rho_in, const FactorProf fprof, const bool fold_in = false) {
   const Shm& sh = sh_in;
   const double* rows = rows_in;
   const int64_t rcap = rcap_in;
   const int32_t* tstart = tstart_in;
+  // h_tail, n_tail: stride and size of the tail the FACTORISATION reduces to and inverts densely.  A folded tail (fold, BIGT only:
+  // AgentDesc::tail_nodes = 12) is that of six nodes at twice the solve's stride; its inverse is then EXPANDED by the last level's
+  // factors to the explicit inverse of the up to twelve nodes at the solve's stride (the end of this function), and the solve
+  // skips that level in both directions.
   const int Nt = Nt_in, Nm = Nt - 1, h_tail = h_tail_in, n_tail = n_tail_in;
+#if CSDO_TAIL_BIG >= 2
+  const bool fold = BIGT && fold_in;
+#else
+  constexpr bool fold = false;   // (the shipped build: the folded tail is compiled out, its code below included - measured slower)
+  (void)fold_in;
+#endif
   const double sigma = sigma_in, rho_now = rho_in;
   // the tail's inverse: row stride and capacity (a constant but for the kernels that read the tail's size at run time, BIGT)
   const int ldt = BIGT ? sh.ld_tinv : (int)LD_tinv;
@@ -604,8 +614,10 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
   CSDO_STHREADS(l, nthr) {
     // (element by element: three elements of a thread at a time with their loads in flight together was measured slower, 61.6
     //  against 61.3 ms - the extra address arithmetic costs more than the trips it saves)
-    for (int e = l; e < tcap * tcap; e += nthr) {
-      const int r = e / tcap, c = e - r * tcap;
+    // (a folded tail: only the corner the six nodes take - the expansion at the end rewrites every element of the inverse)
+    const int acap = fold ? (int)TAIL_N : tcap;
+    for (int e = l; e < acap * acap; e += nthr) {
+      const int r = e / acap, c = e - r * acap;
       const int kn = r / 6, i = r - 6 * kn, jn = kn * h_tail;
       const int kc = c / 6, ic = c - 6 * kc;
       double v = 0.0;
@@ -778,6 +790,105 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
   }
 #endif
+#if CSDO_TAIL_BIG >= 2
+  if constexpr (BIGT && MODE != 3) {
+    if (fold) {
+      // ---- the folded last level.  G6 = inverse of the system of the nodes a * 2hs (hs = h_tail / 2: the solve's stride), in the top
+      // left corner of TINV.  The nodes o = (2 a + 1) hs in between were eliminated at the last level with
+      //   x_o = Sinv_o b_o - T_o x_left - V_o x_right,   b_left -= T_o' b_o,   b_right -= V_o' b_o      (T = Sinv Rl, V = Sinv Rr'),
+      // so the inverse of the system of ALL nodes k hs (k < 12) is, block by block (e, e' even nodes, o, o' odd ones):
+      //   G[e, e'] = G6[e, e']                       G[e, o] = -(G6[e, l(o)] T_o' + G6[e, r(o)] V_o') = G[o, e]'
+      //   G[o, o'] = [o = o'] Sinv_o - T_o G[l(o), o'] - V_o G[r(o), o']
+      // - 2 x 36 x 36 elements of twelve multiply-adds, two passes over all solver threads, instead of a level of the reduction in
+      // every solve (forward and backward: a tenth of an ADMM iteration) or the dense inversion of a 72 x 72 system (round 5:
+      // more than the level gives back).  Scratch: the ADMM block's LDS arrays, dead during the factorisation (G6's copy, then T, V
+      // and Sinv of the odd nodes - from the pair-split solve's factor slots in the workspace, where the level left them).
+      const int hs = h_tail >> 1;
+      double* const s6 = sh.vec + 256;          // [36][36]
+      double* const tv = s6 + 36 * 36;           // per odd node a: T [j][k] at 108 a, V [j][k] at 108 a + 36, Sinv [i][j] at 108 a + 72
+      CSDO_STHREADS(l, nthr) {
+        for (int e = l; e < 36 * 36; e += nthr) {
+          const int r = (e * 1821) >> 16, c = e - 36 * r;   // e / 36 for e < 1296
+          s6[e] = (r < n_tail && c < n_tail) ? TINV(c, r) : 0.0;
+        }
+        for (int e = l; e < 6 * 108; e += nthr) {
+          const int a = (e * 607) >> 16, idx = e - 108 * a;   // e / 108 for e < 648
+          const int to = (2 * a + 1) * hs;
+          double v = 0.0;
+          if (to < Nt) {
+            if (idx < 36) {
+              const int j = idx / 6, k = idx - 6 * j;
+              v = PF_L(k * 6 + j, to);
+            } else if (idx < 72) {
+              const int j = (idx - 36) / 6, k = idx - 36 - 6 * j;
+              v = ((to + hs) < Nt) ? PF_R(k * 6 + j, to) : 0.0;
+            } else {
+              const int i = (idx - 72) / 6, j = idx - 72 - 6 * i;
+              v = WS(W_SINV + ((i >= j) ? (i * (i + 1) / 2 + j) : (j * (j + 1) / 2 + i)), to);
+            }
+          }
+          tv[e] = v;
+        }
+      }
+      CSDO_SYNC();
+      CSDO_STHREADS(l, nthr) {   // the even-even blocks (G6 scattered) and the even-odd blocks with their transposes: every element, zeros included
+        for (int e = l; e < 2 * 36 * 36; e += nthr) {
+          const bool eo = e >= 36 * 36;
+          const int e1 = eo ? e - 36 * 36 : e;
+          const int r = (e1 * 1821) >> 16, c = e1 - 36 * r;
+          const int ra = (r * 43) >> 8, ri = r - 6 * ra, ca = (c * 43) >> 8, cj = c - 6 * ca;
+          const int row = 12 * ra + ri;            // even node ra = node 2 ra of the twelve
+          if (!eo) {
+            TINV(12 * ca + cj, row) = s6[36 * r + c];
+          } else {
+            // column: component cj of odd node ca (node 2 ca + 1 of the twelve); its neighbours among the even nodes: ca and ca + 1
+            const double* const To = tv + 108 * ca + 6 * cj;
+            const double* const Vo = To + 36;
+            const double* const gl = s6 + 36 * r + 6 * ca;
+            const int car = (ca + 1 < 6) ? ca + 1 : ca;   // (no right neighbour: V is zero)
+            const double* const gr = s6 + 36 * r + 6 * car;
+            double tl_[6], vr_[6], g1[6], g2[6];
+            CSDO_FOR(k, 6, {
+              tl_[k] = To[k];
+              vr_[k] = Vo[k];
+              g1[k] = gl[k];
+              g2[k] = gr[k];
+            });
+            double v = 0.0;
+            CSDO_FOR(k, 6, { v = fma(g1[k], tl_[k], v); });
+            CSDO_FOR(k, 6, { v = fma(g2[k], vr_[k], v); });
+            const int col = 12 * ca + 6 + cj;
+            TINV(col, row) = 0.0 - v;
+            TINV(row, col) = 0.0 - v;
+          }
+        }
+      }
+      CSDO_SYNC();
+      CSDO_STHREADS(l, nthr) {   // the odd-odd blocks (zero where a node does not exist: T, V and Sinv are)
+        for (int e = l; e < 36 * 36; e += nthr) {
+          const int r = (e * 1821) >> 16, c = e - 36 * r;
+          const int ra = (r * 43) >> 8, ri = r - 6 * ra, ca = (c * 43) >> 8, cj = c - 6 * ca;
+          const int row = 12 * ra + 6 + ri, col = 12 * ca + 6 + cj;
+          const double* const To = tv + 108 * ra + 6 * ri;
+          const double* const Vo = To + 36;
+          const int rar = (ra + 1 < 6) ? ra + 1 : ra;
+          double tl_[6], vr_[6], g1[6], g2[6];
+          CSDO_FOR(k, 6, {
+            tl_[k] = To[k];
+            vr_[k] = Vo[k];
+            g1[k] = TINV(col, 12 * ra + k);
+            g2[k] = TINV(col, 12 * rar + k);
+          });
+          double v = (ra == ca) ? tv[108 * ra + 72 + 6 * ri + cj] : 0.0;
+          CSDO_FOR(k, 6, { v = fma(-tl_[k], g1[k], v); });
+          CSDO_FOR(k, 6, { v = fma(-vr_[k], g2[k], v); });
+          TINV(col, row) = v;
+        }
+      }
+      CSDO_SYNC();
+    }
+  }
+#endif
   if constexpr (MODE == 3) {   // (node 0 is never eliminated: its lane's blocks are loaded with the others and never used)
     CSDO_TLANES(t) {
       if (t == 0) CSDO_FOR(k, 72, { FE(k, 0) = 0.0; });
@@ -834,6 +945,14 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #define TINV(c, r) sh.tinv[(r) * ldt + (c)]
   while ((Nt + h_tail - 1) / h_tail > tail_cap) h_tail <<= 1;
   const int R_tail = (Nt + h_tail - 1) / h_tail, n_tail = 6 * R_tail;
+  // A twelve-node tail is FOLDED (bcr_factor): the factorisation reduces to the six nodes at twice the stride, inverts those
+  // densely and expands the inverse by the last level's factors; the solve runs on (h_tail, n_tail) as with any other tail.
+#if CSDO_TAIL_BIG >= 2
+  const bool tail_fold = BIGT && MODE != 3 && tail_cap > 8;   // (mode 3, the one-lane form: the dense inversion of all twelve)
+#else
+  constexpr bool tail_fold = false;
+#endif
+  const int h_fac = tail_fold ? 2 * h_tail : h_tail, n_fac = tail_fold ? 6 * ((Nt + h_fac - 1) / h_fac) : n_tail;
   int lg_tail = 0;
   while ((1 << lg_tail) < h_tail) ++lg_tail;
   (void)lg_tail;
@@ -1311,7 +1430,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
 #else
       const FactorProf fprof{};
 #endif
-      bcr_factor<ROLE, MODE, BIGT>(sh, rows, rcap, tstart, Nt, h_tail, n_tail, sigma, rho_now, fprof);
+      bcr_factor<ROLE, MODE, BIGT>(sh, rows, rcap, tstart, Nt, h_fac, n_fac, sigma, rho_now, fprof, tail_fold);
     };
 
     // ============================================================== BCR solve on the solver lanes.

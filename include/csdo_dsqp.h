@@ -353,7 +353,7 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p);
 
 /* Library identification: returns "hip-gfx950". */
 const char* csdo_backend_name(void);
-/* The first 16 hex digits of the SHA-256 over the device sources (csrc/*.h, csrc/*.hip, this header) the library was built from
+/* The first 16 hex digits of the SHA-256 over the device sources (the headers and .hip files of csrc/, this header) the library was built from
  * (csrc/Makefile: CSDO_SOURCE_HASH).  bench.py prints it, scripts/summarize_profiles.py stores it with every counter summary under
  * profiles/, and bench.py only quotes a summary's counter figures when the two agree: counters of another kernel are not evidence. */
 const char* csdo_source_hash(void);

@@ -1,5 +1,5 @@
 """Runs every solver of the chain-parity report on a whole workload and caches the per-agent results (solutions, corridors, counts) under
-oracle/_cache/ (git-ignored): the binary128 arbiter takes minutes per workload, the reports that read it (scripts/chain_parity.py,
+$CSDO_ARBITER_CACHE (default /tmp/csdo_arbiter_cache: outside the tree): the binary128 arbiter takes minutes per workload, the reports that read it (scripts/chain_parity.py,
 tests/golden/make_arbiter_fixture.py) seconds.   python scripts/arbiter_run.py --workload map100 [--solvers q,qxm,oracle,...]"""
 import argparse
 import os
@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-CACHE = os.path.join(ROOT, "oracle", "_cache")
+CACHE = os.environ.get("CSDO_ARBITER_CACHE", "/tmp/csdo_arbiter_cache")   # outside the tree: gpurun ships the whole tree to the GPU box
 ALL = ("product", "oracle", "oracle_fma", "oracle_xm", "oracle_ld", "oracle_q", "oracle_qxm")
 
 
@@ -39,6 +39,22 @@ def pack(sols):
             "sqp_iters": np.concatenate([s.sqp_iters for s in sols]), "admm_iters": np.concatenate([s.admm_iters for s in sols]),
             "last_status": np.concatenate([s.last_status for s in sols]),
             "Na": np.array([s.solutions.shape[0] for s in sols]), "Nt": np.array([s.solutions.shape[1] for s in sols])}
+
+
+def unpack(z):
+    """The inverse of pack: one object per world with the arrays the reports read."""
+    class S:
+        pass
+    out, o6, o8, oa = [], 0, 0, 0
+    for na, nt in zip(z["Na"], z["Nt"]):
+        na, nt = int(na), int(nt)
+        s = S()
+        s.solutions = z["solutions"][o6:o6 + na * nt * 6].reshape(na, nt, 6)
+        s.corridors = z["corridors"][o8:o8 + na * nt * 8].reshape(na, nt, 8)
+        s.sqp_iters, s.admm_iters, s.last_status = z["sqp_iters"][oa:oa + na], z["admm_iters"][oa:oa + na], z["last_status"][oa:oa + na]
+        o6, o8, oa = o6 + na * nt * 6, o8 + na * nt * 8, oa + na
+        out.append(s)
+    return out
 
 
 def cache_path(workload, name):

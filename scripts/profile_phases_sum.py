@@ -6,7 +6,8 @@ import sys
 import numpy as np
 sys.path.insert(0, '.')
 from csdotrajectoryplanning_amd import _lib, workloads  # noqa: E402
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("CSDO_PROF_LIB", "libcsdo_hip_prof.so"))
+if not os.environ.get("CSDO_DIAG_LIB"):      # (CSDO_DIAG_LIB: a phase-timer build given by path, scripts/gpu_run.sh phases:<workload>:<lib>)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("CSDO_PROF_LIB", "libcsdo_hip_prof.so"))
 from csdotrajectoryplanning_amd.solver import DsqpHandle  # noqa: E402
 NAMES = ["other", "corridor", "assemble", "ruiz", "warmstart", "factor", "rhs", "solve_fwd", "solve_bwd", "update",
          "info/check", "bookkeeping", "hot load/save", "fwd barrier", "bwd barrier", "-"]

@@ -1,0 +1,215 @@
+"""Where does the product's linear solve lose accuracy against OSQP's?  (round 6, behind the arbiter's finding that the product is
+~2.5 x further from the exact-arithmetic iterate path than a double-precision OSQP.)  Numpy experiment on the assembled agent QPs of
+the OSQP pin kit (tests/golden/osqp_pin): one ADMM linear solve  [P + sigma I, A'; A, -1/rho] [x; nu] = [rhs_x; rhs_z]  by
+  kkt      SuperLU on the quasi-definite KKT matrix in double (what OSQP's LDL' does, up to the pivoting)
+  chol     dense Cholesky of the reduced matrix H = P + sigma I + A' R A in double (a backward-stable solve of the product's formulation)
+  bcr      block cyclic reduction of H with explicit 6x6 pivot inverses and pre-multiplied couplings, dense tail (the product's algorithm,
+           restated in numpy: same formulas, not the same order of additions)
+  bcr+ir   bcr followed by one step of iterative refinement, residual formed through A in double (r = b - (P + sigma) x - A' (R (A x)))
+  bcr+nw   bcr whose pivot inverses got one Newton step  X <- X (2 I - S X)
+against a reference obtained by iterative refinement in x87 extended precision to convergence.  Reports max |x - x_ref| (scaled variables).
+   python scripts/solve_accuracy.py [qp indices]"""
+import os
+import sys
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import admm_numpy as an      # noqa: E402
+
+LD = np.longdouble
+
+
+def scaled_qp(z):
+    n, m = int(z["n"]), int(z["m"])
+    Pu = sp.csc_matrix((z["P_data"], z["P_indices"], z["P_indptr"]), shape=(n, n))
+    P = sp.csc_matrix(Pu + sp.triu(Pu, 1).T)
+    A = sp.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=(m, n))
+    q, l, u = np.array(z["q"], float), np.array(z["l"], float), np.array(z["u"], float)
+    D, E, c = np.ones(n), np.ones(m), 1.0
+    for _ in range(10):
+        dD = 1.0 / np.sqrt(an._limit(np.maximum(an._inf_norm_cols(P), an._inf_norm_cols(A))))
+        dE = 1.0 / np.sqrt(an._limit(an._inf_norm_cols(A.T)))
+        P = sp.csc_matrix(sp.diags(dD) @ P @ sp.diags(dD))
+        A = sp.csc_matrix(sp.diags(dE) @ A @ sp.diags(dD))
+        q = dD * q
+        D, E = dD * D, dE * E
+        gamma = max(float(np.mean(an._inf_norm_cols(P))), float(an._limit(np.array([an._ninf(q)]))[0]))
+        gamma = 1.0 / float(an._limit(np.array([gamma]))[0])
+        P, q, c = P * gamma, q * gamma, c * gamma
+    l, u = E * l, E * u
+    loose = (l < -an.INFTY * an.MIN_SCALING) & (u > an.INFTY * an.MIN_SCALING)
+    eq = ~loose & (u - l < an.RHO_TOL)
+    return P, A, q, l, u, D, E, loose, eq
+
+
+def H_longdouble(P, A, rv, sigma):
+    n = P.shape[0]
+    H = np.zeros((n, n), LD)
+    Pc = P.tocoo()
+    H[Pc.row, Pc.col] += Pc.data.astype(LD)
+    H[np.arange(n), np.arange(n)] += LD(sigma)
+    Ar = A.tocsr()
+    for i in range(A.shape[0]):
+        lo, hi = Ar.indptr[i], Ar.indptr[i + 1]
+        j, v = Ar.indices[lo:hi], Ar.data[lo:hi].astype(LD)
+        H[np.ix_(j, j)] += LD(rv[i]) * np.outer(v, v)
+    return H
+
+
+def bcr_solve_factory(H, n_blocks, newton=False, tail_nodes=6):
+    """Block cyclic reduction of the block-tridiagonal H (6x6 blocks; the last block may be 4x4: padded with identity)."""
+    nb = n_blocks
+    N = 6 * nb
+    Hp = np.eye(N)
+    n = H.shape[0]
+    Hp[:n, :n] = H
+    Dg = [Hp[6 * t:6 * t + 6, 6 * t:6 * t + 6].copy() for t in range(nb)]
+    Rt = [Hp[6 * t + 6:6 * t + 12, 6 * t:6 * t + 6].copy() if t + 1 < nb else None for t in range(nb)]   # coupling to the right neighbour: rows right, cols own
+    levels = []
+    alive = list(range(nb))
+    h = 1
+    while len(alive) > tail_nodes:
+        elim = alive[1::2]
+        surv = alive[0::2]
+        pos = {t: k for k, t in enumerate(alive)}
+        lev = {}
+        newD = {t: Dg[t].copy() for t in surv}
+        newR = {}
+        for t in elim:
+            S = Dg[t]
+            X = np.linalg.inv(S)        # (explicit inverse; the product: Gauss-Jordan on the SPD block)
+            if newton:
+                X = X @ (2 * np.eye(6) - S @ X)
+            k = pos[t]
+            tl = alive[k - 1]
+            tr = alive[k + 1] if k + 1 < len(alive) else None
+            El = Rt[tl]                 # rows t, cols tl  (H[t, tl])
+            Fl = X @ El                 # x_t = w - Fl x_tl - Fr' x_tr
+            lev[t] = dict(Sinv=X, tl=tl, tr=tr, Fl=Fl)
+            newD[tl] = newD[tl] - El.T @ Fl
+            if tr is not None:
+                Er = Rt[t]              # rows tr, cols t  (H[tr, t])
+                Fr = Er @ X             # b_tr -= Fr b_t
+                lev[t]["Fr"] = Fr
+                newD[tr] = newD[tr] - Fr @ Er.T
+                newR[tl] = -(Er @ Fl)   # new coupling H'[tr, tl]
+        for t in surv:
+            Dg[t] = newD[t]
+            if t in newR:
+                Rt[t] = newR[t]
+            elif pos[t] + 2 >= len(alive):
+                Rt[t] = None
+        levels.append(lev)
+        alive = surv
+    # dense tail
+    nt_ = len(alive)
+    T = np.zeros((6 * nt_, 6 * nt_))
+    for k, t in enumerate(alive):
+        T[6 * k:6 * k + 6, 6 * k:6 * k + 6] = Dg[t]
+        if k + 1 < nt_:
+            T[6 * k + 6:6 * k + 12, 6 * k:6 * k + 6] = Rt[t]
+            T[6 * k:6 * k + 6, 6 * k + 6:6 * k + 12] = Rt[t].T
+    Tinv = np.linalg.inv(T)
+
+    def solve(b):
+        bp = np.zeros(N)
+        bp[:n] = b
+        B = [bp[6 * t:6 * t + 6].copy() for t in range(nb)]
+        for lev in levels:
+            for t, f in lev.items():
+                B[f["tl"]] = B[f["tl"]] - f["Fl"].T @ B[t]
+            for t, f in lev.items():
+                if f["tr"] is not None:
+                    B[f["tr"]] = B[f["tr"]] - f["Fr"] @ B[t]
+        xt = Tinv @ np.concatenate([B[t] for t in alive])
+        X = [None] * nb
+        for k, t in enumerate(alive):
+            X[t] = xt[6 * k:6 * k + 6]
+        for lev in reversed(levels):
+            for t, f in lev.items():
+                x = f["Sinv"] @ B[t] - f["Fl"] @ X[f["tl"]]
+                if f["tr"] is not None:
+                    x = x - f["Fr"].T @ X[f["tr"]]
+                X[t] = x
+        return np.concatenate(X)[:n]
+    return solve
+
+
+def main():
+    idx = [int(a) for a in sys.argv[1:]] or [0, 3, 7, 13, 14, 19]
+    sigma = 1e-6
+    print("%-6s %-5s %-9s %-9s | max |x - x_ref| (scaled x), |x_ref|_inf: kkt, chol, bcr, bcr+ir, bcr+nw, bcr12" % ("qp", "n", "rho", "cond(H)"))
+    for k in idx:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "osqp_pin", "qp_%02d.npz" % k))
+        P, A, q, l, u, D, E, loose, eq = scaled_qp(z)
+        n, m = P.shape[0], A.shape[0]
+        Nt = (n + 2) // 6
+        for rho in (0.1, 0.005):
+            rv = np.where(loose, an.RHO_MIN, np.where(eq, an.RHO_EQ * rho, rho))
+            rng = np.random.default_rng(k)
+            # a realistic right-hand side: the first iteration's from the warm start, plus dual / slack noise of the size a mid-solve has
+            x0 = np.array(z["x_warm"], float) / D
+            z0 = A @ x0
+            y0 = rng.normal(size=m) * 1e-2
+            rhs_x = sigma * x0 - q
+            rhs_z = z0 - y0 / rv
+            # reduced rhs: b = rhs_x + A' (R rhs_z)
+            b = rhs_x + A.T @ (rv * rhs_z)
+            H = (P + sigma * sp.identity(n) + A.T @ sp.diags(rv) @ A).toarray()
+            Hl = H_longdouble(P, A, rv, sigma)
+            bl = rhs_x.astype(LD) + (A.T.tocsr().astype(float) @ np.zeros(m)).astype(LD)     # (placeholder, replaced below)
+            Ar = A.tocsr()
+            t_ = (rv.astype(LD) * rhs_z.astype(LD))
+            bl = rhs_x.astype(LD).copy()
+            for i in range(m):
+                lo, hi = Ar.indptr[i], Ar.indptr[i + 1]
+                bl[Ar.indices[lo:hi]] += Ar.data[lo:hi].astype(LD) * t_[i]
+            cf = sla.cho_factor(H)
+            xr = sla.cho_solve(cf, np.asarray(bl, float)).astype(LD)
+            for _ in range(8):                                    # refinement in extended precision to convergence
+                r = bl - Hl @ xr
+                xr = xr + sla.cho_solve(cf, np.asarray(r, float)).astype(LD)
+            ref = np.asarray(xr, float)
+            res = {}
+            K = sp.bmat([[P + sigma * sp.identity(n), A.T], [A, -sp.diags(1.0 / rv)]], format="csc")
+            res["kkt"] = spla.splu(K).solve(np.concatenate([rhs_x, rhs_z]))[:n]
+            res["chol"] = sla.cho_solve(cf, b)
+            # the QP's variables are field-major ([x(Nt), y(Nt), yaw(Nt), steer(Nt), v(Nt-1), w(Nt-1)]); BCR works time-major
+            Nm = Nt - 1
+            perm = []
+            for t in range(Nt):
+                perm += [t, Nt + t, 2 * Nt + t, 3 * Nt + t] + ([4 * Nt + t, 4 * Nt + Nm + t] if t < Nm else [])
+            perm = np.array(perm)
+            Hp = H[np.ix_(perm, perm)]
+
+            def timemajor(f):
+                def g(bb):
+                    out = np.zeros(n)
+                    out[perm] = f(bb[perm])
+                    return out
+                return g
+            bs = timemajor(bcr_solve_factory(Hp, Nt))
+            res["bcr"] = bs(b)
+            xb = res["bcr"]
+            r = b - ((P @ xb) + sigma * xb + A.T @ (rv * (A @ xb)))
+            res["bcr+ir"] = xb + bs(r)
+            res["bcr+irH"] = xb + bs(b - H @ xb)          # residual through the formed H (double) instead of through A
+            res["bcr+nw"] = timemajor(bcr_solve_factory(Hp, Nt, newton=True))(b)
+            res["bcr12"] = timemajor(bcr_solve_factory(Hp, Nt, tail_nodes=12))(b)
+            # where the reduced formulation loses its digits: forming H, forming b, or the solve itself?
+            cfl = sla.cho_factor(np.asarray(Hl, float))
+            res["chol(Hx,b)"] = sla.cho_solve(cfl, b)
+            res["chol(H,bx)"] = sla.cho_solve(cf, np.asarray(bl, float))
+            res["chol(Hx,bx)"] = sla.cho_solve(cfl, np.asarray(bl, float))
+            cond = np.linalg.cond(H)
+            print("qp_%02d  %-5d %-9.3g %-9.2e | %.2e : %s" % (k, n, rho, cond, np.abs(ref).max(),
+                  "  ".join("%s %.2e" % (nm, np.abs(v - ref).max()) for nm, v in res.items())))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,8 @@ def lib():
     global _LIB
     if _LIB is None:
         build()
-        _LIB = C.CDLL(os.path.join(_ROOT, "tests", "emu", "libcsdo_emu.so"))
+        # CSDO_EMU_LIB: another build of the same source (experiments: scripts/emu_regress.py, scripts/chain_parity.py)
+        _LIB = C.CDLL(os.environ.get("CSDO_EMU_LIB") or os.path.join(_ROOT, "tests", "emu", "libcsdo_emu.so"))
         _LIB.csdo_emu_solve_batch.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result)]
         _LIB.csdo_emu_solve_batch_mode.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int]
         _LIB.csdo_emu_solve_batch_mt.argtypes = [C.POINTER(abi.Problem), C.c_int32, C.POINTER(abi.Result), C.c_int,

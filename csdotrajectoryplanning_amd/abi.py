@@ -28,7 +28,7 @@ class QpParm(C.Structure):
                 ("max_iter", C.c_double), ("delta_solution_threshold", C.c_double),
                 ("max_violation", C.c_double), ("osqp_max_iter", C.c_int32),
                 ("num_interpolation", C.c_int32), ("dt", C.c_double), ("fixed_corridor", C.c_int32),
-                ("adaptive_rho_interval", C.c_int32)]
+                ("adaptive_rho_interval", C.c_int32), ("solve_refinement", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class Plane(C.Structure):

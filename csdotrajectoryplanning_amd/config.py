@@ -33,7 +33,7 @@ def vehicle_from_config(cfg=None) -> Vehicle:
     return v
 
 
-def qp_parm_from_config(cfg=None, adaptive_rho_interval=25) -> QpParm:
+def qp_parm_from_config(cfg=None, adaptive_rho_interval=25, solve_refinement=0) -> QpParm:
     cfg = {**DEFAULT_CONFIG, **(cfg or {})}
     p = QpParm()
     p.r_trust = float(cfg["r_trust"])
@@ -49,6 +49,7 @@ def qp_parm_from_config(cfg=None, adaptive_rho_interval=25) -> QpParm:
     p.dt = step / p.max_v / (p.num_interpolation + 1) / float(cfg["decelerate_factor"])
     p.fixed_corridor = int(bool(cfg["fixed_corridor"]))
     p.adaptive_rho_interval = int(adaptive_rho_interval)
+    p.solve_refinement = int(bool(solve_refinement))   # csdo_qp_parm::solve_refinement (include/csdo_dsqp.h): the accurate solve, ~2 x the time
     return p
 
 

@@ -1465,6 +1465,8 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p) {
   p->dt = step / p->max_v / (p->num_interpolation + 1) / 0.8;
   p->fixed_corridor = 0;
   p->adaptive_rho_interval = 25;
+  p->solve_refinement = 0;
+  p->_reserved = 0;
 }
 
 #if defined(CSDO_PROFILE_PHASES)

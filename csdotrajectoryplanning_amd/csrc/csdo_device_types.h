@@ -45,6 +45,7 @@ struct SolverParams {
   // QpParm (sqp/common.h:39-52)
   double r_trust, max_omega, max_v, delta_solution_threshold, dt;
   int32_t max_iter, osqp_max_iter, fixed_corridor, adaptive_rho_interval;
+  int32_t solve_refinement, pad_;   // csdo_qp_parm::solve_refinement: which kernel instantiations a launch uses (REFINE)
   // OSQP 0.6.3 defaults (osqp_set_default_settings)
   double rho0, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
   int32_t scaling_passes, check_termination;

@@ -114,7 +114,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
 #if !defined(CSDO_PRIO_SOLVER)
 #define CSDO_PRIO_SOLVER 2
 #endif
-template <int BLOCK, int MODE, bool SPLIT>
+template <int BLOCK, int MODE, bool SPLIT, bool REFINE = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kernel(const DeviceBatch B, const int first, const int count,
                                                              int* __restrict__ queue, const int lds_doubles) {
   extern __shared__ __align__(16) double lds[];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
       ProgramOut po;
       RowRegs lr;
       SolvRegs ls_unused;
-      agent_program<ROLE_ROW, MODE, (BLOCK == 512)>(B, agent, sh, lr, ls_unused, po);
+      agent_program<ROLE_ROW, MODE, (BLOCK == 512), REFINE>(B, agent, sh, lr, ls_unused, po);
       if (threadIdx.x == 0) {
         B.sqp_iters[agent] = po.sqp_iters;
         B.admm_iters[agent] = po.admm_iters;
@@ -169,14 +169,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
       ProgramOut po;
       RowRegs lr_unused;
       SolvRegs ls;
-      agent_program<ROLE_SOLVER, MODE, (BLOCK == 512)>(B, agent, sh, lr_unused, ls, po);
+      agent_program<ROLE_SOLVER, MODE, (BLOCK == 512), REFINE>(B, agent, sh, lr_unused, ls, po);
     }
   }
 }
 
-template <int BLOCK, int MODE, bool SPLIT>
+template <int BLOCK, int MODE, bool SPLIT, bool REFINE>
 hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream) {
-  auto kernel = dsqp_agent_kernel<BLOCK, MODE, SPLIT>;
+  auto kernel = dsqp_agent_kernel<BLOCK, MODE, SPLIT, REFINE>;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(BLOCK), g.lds_bytes, stream, B, g.first, g.count, g.queue,

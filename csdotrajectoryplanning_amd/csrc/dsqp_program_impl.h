@@ -906,7 +906,9 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
 #undef TINV
 
 // =========================================================================================================
-template <int ROLE, int MODE, bool BIGT, class RowStore, class SolvStore>
+// REFINE (csdo_qp_parm::solve_refinement; separate kernel instantiations, compiled out of the default ones): every ADMM iteration's
+// linear solve is followed by ONE step of iterative refinement on the residual of the KKT system - see "refinement" in the iteration.
+template <int ROLE, int MODE, bool BIGT, bool REFINE = false, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out) {
   AgentDesc ad = B.agents[agent];
@@ -2568,6 +2570,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (rows_lds) add_planes(std::true_type{});
           else add_planes(std::false_type{});
           CSDO_FOR(j, 6, { V.b[j] = r6[j]; });
+          if constexpr (REFINE) CSDO_FOR(j, 6, { V.b0[j] = r6[j]; });
         }
         // (modes 2, 3: the row lanes stream their rows' coefficients and bounds from the workspace, see the update; on the device the
         //  first two groups of rows are fetched while the row waves wait for the backward sweep)
@@ -2603,6 +2606,86 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             }
           }
         });
+        static_assert(!REFINE || !CSDO_TS_LDS, "the refinement keeps the plane ranges in the solver lanes' registers");
+        if constexpr (REFINE) {
+          // ---- refinement (csdo_qp_parm::solve_refinement).  The reduced system H x = b, H = P + sigma I + A' R A, has the condition
+          // of A' R A: a backward-stable solve of it - block cyclic reduction behaves like a Cholesky factorisation here - returns
+          // x~ with |error| ~ cond(H) eps |x|, some fifty times the error of OSQP's LDL' of the quasi-definite KKT matrix
+          // (scripts/solve_accuracy.py: 2e-12 .. 2e-11 against 3e-14 .. 3e-13 on the agent QPs of the pin kit), and over an SQP chain
+          // that puts 1.3 - 1.5 times as many agents beyond 1e-4 of the exact-arithmetic path as a double-precision OSQP
+          // (scripts/chain_parity.py).  One step of iterative refinement closes the gap IF the residual is that of
+          // the KKT system, i.e. formed through A - r = b - (P + sigma) x~ - A' (R (A x~)), the large rho-weighted terms entering as
+          // products of small numbers - and not through the formed blocks of H (measured: no gain).  Then x~ += H^-1 r with the same
+          // factor: 3e-14 .. 2e-13.  Cost: a second solve and a pass over the rows per iteration, about twice the time.
+          CSDO_LANES_HOT(t) {   // the home rows' share of H x~ (own columns -> rhs, column i of t + 1 -> carry; the arrays' contents
+            LaneState& S = CSDO_LS(t);   // went into b, which the solver lane kept)
+            double xt[6], xn[4] = {0, 0, 0, 0};
+            CSDO_FOR(k, 6, { xt[k] = SH(vec, k, t); });
+            if (t < Nm) CSDO_FOR(k, 4, { xn[k] = SH(vec, k, t + 1); });
+            const double vnext = (t < Nm) ? SH(vec, 4, t + 1) : 0.0;
+            const double pvv = WS(W_P + 0, t), pww = WS(W_P + 1, t), pvn = WS(W_P + 2, t);
+            double r6[6], kin[4] = {0, 0, 0, 0};
+            CSDO_FOR(j, 6, { r6[j] = (j < S.ncols) ? sigma * xt[j] : xt[j]; });   // (the padding of the last node: identity)
+            r6[4] = fma(pvv, xt[4], r6[4]);     // P: the first-difference Laplacian on v (its coupling to t - 1: the solver lane below) ...
+            r6[4] = fma(pvn, vnext, r6[4]);
+            r6[5] = fma(pww, xt[5], r6[5]);     // ... and the identity on w
+            CSDO_FOR(i, NROW, {
+              double ci[3] = {0, 0, 0}, cni = 0.0;
+              if constexpr (MODE < 2) {
+                CSDO_FOR(s_, 3, { ci[s_] = S.c[i][s_]; });
+                if constexpr (i < 4) cni = S.cn[i];
+              } else {   // (the long-horizon classes stream the coefficients: from the workspace here)
+                CSDO_FOR(s_, 3, {
+                  if constexpr (row_col(i, s_) >= 0) ci[s_] = WS(W_C + 3 * i + s_, t);
+                });
+                if constexpr (i < 4) cni = WS(W_CN + i, t);
+              }
+              double zt = 0.0;
+              CSDO_FOR(s_, 3, {
+                if constexpr (row_col(i, s_) >= 0) zt = fma(ci[s_], xt[row_col(i, s_)], zt);
+              });
+              if constexpr (i < 4) zt = fma(cni, xn[i], zt);
+              const double g = rho_row<i>(S, rho, rho_eq) * zt;
+              CSDO_FOR(s_, 3, {
+                if constexpr (row_col(i, s_) >= 0) r6[row_col(i, s_)] = fma(ci[s_], g, r6[row_col(i, s_)]);
+              });
+              if constexpr (i < 4) kin[i] = cni * g;
+            });
+            CSDO_FOR(j, 6, { SH(rhs, j, t) = r6[j]; });
+            CSDO_FOR(k, 4, { SH(carry, k, t) = kin[k]; });
+          }
+          CSDO_SYNC();
+          CSDO_SLANES(t) {   // r = b - H x~: the rows' shares, the hand-over from t - 1 and this timestep's inter-vehicle rows
+            SolvRegs& V = CSDO_SS(t);
+            double h6[6], x3[3];
+            CSDO_FOR(j, 6, { h6[j] = SH(rhs, j, t); });
+            CSDO_FOR(k, 3, { x3[k] = SH(vec, k, t); });
+            CSDO_FOR(k, 6, { V.x0[k] = SH(vec, k, t); });
+            if (t > 0) {
+              CSDO_FOR(k, 4, { h6[k] += SH(carry, k, t - 1); });
+              h6[4] = fma(WS(W_P + 2, t - 1), SH(vec, 4, t - 1), h6[4]);
+            }
+            for (int p = V.ts0; p < V.ts1; ++p) {
+              CSDO_FOR(q, 4, {
+                const double a = ROW(4 * p + q, R_CA), bb = ROW(4 * p + q, R_CB), cy = ROW(4 * p + q, R_CY);
+                const double g = rho * ((a * x3[0] + bb * x3[1]) + cy * x3[2]);
+                h6[0] = fma(a, g, h6[0]);
+                h6[1] = fma(bb, g, h6[1]);
+                h6[2] = fma(cy, g, h6[2]);
+              });
+            }
+            CSDO_FOR(j, 6, { V.b[j] = V.b0[j] - h6[j]; });
+          }
+          CSDO_SYNC();
+          solve([]() __attribute__((always_inline)) {});
+          CSDO_SLANES(t) {
+            SolvRegs& V = CSDO_SS(t);
+            double dx[6];
+            CSDO_FOR(k, 6, { dx[k] = SH(vec, k, t); });
+            CSDO_FOR(k, 6, { SH(vec, k, t) = V.x0[k] + dx[k]; });
+          }
+          CSDO_SYNC();
+        }
         CSDO_PHASE(9);
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test
         CSDO_MARK("update");

@@ -185,6 +185,8 @@ inline bool load_config(const std::string& path, csdo_vehicle* veh, csdo_qp_parm
     parm->dt = step / parm->max_v / (parm->num_interpolation + 1) / num("decelerate_factor", 0.8);
     parm->fixed_corridor = num("fixed_corridor", 0) != 0 ? 1 : 0;
     parm->adaptive_rho_interval = 25;
+    parm->solve_refinement = 0;
+    parm->_reserved = 0;
   }
   if (front) {
     csdo_front_end_parm_default(front);

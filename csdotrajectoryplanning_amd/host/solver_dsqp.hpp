@@ -46,7 +46,9 @@ class SolverDSQP {
   SolverDSQP(std::vector<std::vector<OptRes>>& solutions, const std::vector<std::vector<OptRes>>& x0_bar,
              const std::vector<std::vector<Plane>>& inter_planes, double dimx, double dimy,
              const ObstacleRange& obstacles, const Parm& param, int logger_level = 2, int device = 0,
-             const csdo_vehicle* vehicle = nullptr, const std::vector<int>& devices = {}) {
+             const csdo_vehicle* vehicle = nullptr, const std::vector<int>& devices = {}, bool solve_refinement = false) {
+    // solve_refinement: csdo_qp_parm::solve_refinement - every linear solve refined on the KKT residual (as accurate as OSQP's LDL',
+    // about twice the kernel time); no reference counterpart
     // devices: several GPU ordinals - the agents are cut into contiguous blocks of equal estimated work, one per device
     // (csdo_dsqp_create_multi; the loop that shards is sqp/dsqp_solver.cc:1198-1220); empty: the one GPU `device`
     const int Na = (int)x0_bar.size();
@@ -98,6 +100,8 @@ class SolverDSQP {
     P.parm.dt = param.dt;
     P.parm.fixed_corridor = param.fixed_corridor ? 1 : 0;
     P.parm.adaptive_rho_interval = 0;  // documented default (25)
+    P.parm.solve_refinement = solve_refinement ? 1 : 0;
+    P.parm._reserved = 0;
     P.logger_level = logger_level;
 
     std::vector<double> sol((size_t)Na * Nt * 6), cor((size_t)Na * Nt * 8);

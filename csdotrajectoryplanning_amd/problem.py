@@ -36,6 +36,13 @@ class World:
     def Nt(self):
         return int(self.x0_bar.shape[1])
 
+    def with_parm(self, **fields) -> "World":
+        """The same world with fields of its csdo_qp_parm changed (max_iter, solve_refinement, adaptive_rho_interval, ...)."""
+        p = abi.QpParm.from_buffer_copy(bytes(self.parm))
+        for k, v in fields.items():
+            setattr(p, k, type(getattr(p, k))(v))
+        return World(self.x0_bar, self.plane_off, self.planes, self.dimx, self.dimy, self.obstacles, self.veh, p, self.logger_level)
+
     def c_problem(self) -> abi.Problem:
         p = abi.Problem()
         p.Na, p.Nt = self.Na, self.Nt

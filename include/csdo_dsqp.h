@@ -78,6 +78,16 @@ typedef struct csdo_qp_parm {
   /* OSQP's default adaptive_rho_interval = 0 chooses the rho-update period from wall-clock timing; this backend
    * pins it (0 here means the documented default, 25). */
   int32_t adaptive_rho_interval;
+  /* Round 6, no reference counterpart: 1 = every ADMM iteration's linear solve is followed by one step of iterative refinement on the
+   * residual of OSQP's KKT system (formed through the constraint rows, not through the reduced matrix).  The backend solves the
+   * REDUCED system (P + sigma I + A' R A) x = b by block cyclic reduction, whose error is cond(H) eps |x| - about fifty times that
+   * of OSQP's LDL' of the quasi-definite KKT matrix; over an SQP chain that leaves 1.3 - 1.5 times as many agents beyond 1e-4 of
+   * the exact-arithmetic iterate path as a double-precision OSQP is (scripts/chain_parity.py against the binary128
+   * arbiter).  With the refinement the solve is as accurate as OSQP's and the count drops to OSQP's own; it costs a second solve and a
+   * pass over the rows per iteration (about twice the kernel time; separate kernel instantiations, the default ones are unchanged).
+   * 0 (default): off. */
+  int32_t solve_refinement;
+  int32_t _reserved;
 } csdo_qp_parm;
 
 /* InterPlane (sqp/inter_agent_cons.h:47-63): c = {a_f2f,b_f2f,c_f2f, a_f2r,b_f2r,c_f2r, a_r2f,.., a_r2r,b_r2r,c_r2r} */

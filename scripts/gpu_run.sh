@@ -7,6 +7,7 @@
 #     ab:<workloads>:<libA>,<libB>[,...]    interleaved A/B timing (scripts/ab_bench.py), one table per workload
 #     single:<lib>[,<lib>...]               one 50-agent instance alone (scripts/single_instance_times.py)
 #     phases:<workload>[:<lib>]             in-kernel phase profile (prof build or the library given)
+#     refined:<workload>[,...]              bench lines with csdo_qp_parm::solve_refinement = 1
 #     profile:<workload>                    rocprofv3 kernel trace + PMC passes (scripts/profile_round.sh), summaries into profiles/ by collect
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -52,6 +53,11 @@ PY
       CSDO_DIAG_LIB=${lib:-csdotrajectoryplanning_amd/libcsdo_hip_prof.so} timeout 900 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 $w > $O/phases_${w}_$tagl.txt 2>&1; head -12 $O/phases_${w}_$tagl.txt ;;
     profile)
       bash scripts/profile_round.sh $TAG $arg ;;
+    refined)   # what csdo_qp_parm::solve_refinement costs: the same bench lines with the flag on
+      for w in ${arg//,/ }; do
+        timeout 600 python bench.py --workload $w --solve-refinement --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_refined_$w.json 2> $O/bench_refined_$w.err; echo "bench refined $w rc=$?"
+        python -c "import json,sys; d=json.load(open(sys.argv[1])); print('  refined %s: %.2f M it/s  %.2f ms/step  single %.2f ms' % (sys.argv[2], d['value']/1e6, d['ms_per_step'], d['single_instance']['do_phase_ms']['solve_kernel']))" $O/bench_refined_$w.json $w
+      done ;;
     *) echo "unknown step $step" ;;
   esac
 done

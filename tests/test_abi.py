@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts():
     assert C.sizeof(abi.Plane) == 104
     assert C.sizeof(abi.Vehicle) == 80
-    assert C.sizeof(abi.QpParm) == 6 * 8 + 2 * 4 + 8 + 2 * 4
+    assert C.sizeof(abi.QpParm) == 6 * 8 + 2 * 4 + 8 + 2 * 4 + 2 * 4 and abi.QpParm.solve_refinement.offset == 72
     assert abi.Problem.x0_bar.offset == 8 and abi.Problem.dimx.offset == 32
     assert C.sizeof(abi.Result) == 5 * 8 + 2 * 4 + 3 * 8 + 8 and abi.Result.agent_seconds.offset == 72
     assert C.sizeof(abi.LaunchGroup) == 4 * 4 + 8 + 8

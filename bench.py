@@ -587,8 +587,19 @@ def main():
         ok_w = ok_obs = 0
         veh_hits = obs_hits = 0
         t_v0 = time.perf_counter()
-        for w, s_ in zip(worlds, sols):
+        colliding = []      # WHO collides, and how their solves ended: per world with a hit, from the numpy validator
+        from csdotrajectoryplanning_amd import results as results_mod
+        for wi_, (w, s_) in enumerate(zip(worlds, sols)):
             rep = h.validate(s_.solutions, w.veh, w.obstacles, w.dimx, w.dimy)
+            if rep.vehicle_collisions or rep.obstacle_collisions:
+                who = {}
+                results_mod.validate(s_.solutions, w.veh, w.obstacles, w.dimx, w.dimy, participants=who)
+                agents_ = sorted({a_ for i_, j_, _ in who.get("vehicle_pairs", []) for a_ in (i_, j_)} |
+                                 {a_ for a_, _ in who.get("obstacle_agents", [])})
+                colliding.append({"world": wi_, "instance": infos[wi_].get("instance"),
+                                  "vehicle_pairs": who.get("vehicle_pairs", []), "obstacle_agents": who.get("obstacle_agents", []),
+                                  "agents": [{"agent": a_, "last_status": int(s_.last_status[a_]), "sqp_iterations": int(s_.sqp_iters[a_]),
+                                              "admm_iterations": int(s_.admm_iters[a_])} for a_ in agents_]})
             ok_w += int(rep.ok)
             ok_obs += int(rep.obstacle_collisions == 0 and rep.out_of_map == 0)
             veh_hits += rep.vehicle_collisions
@@ -598,6 +609,10 @@ def main():
                       "obstacle_collision_triples": int(obs_hits), "solver_status_ok_worlds":
                           int(sum(1 for s_ in sols if abs(int(s_.solver_status)) <= 2)),
                       "validator_ms": (time.perf_counter() - t_v0) * 1e3,
+                      "colliding": colliding,
+                      "colliding_agents_by_last_status": {str(k_): v_ for k_, v_ in sorted(
+                          __import__("collections").Counter(a_["last_status"] for c_ in colliding for a_ in c_["agents"]).items())},
+                      "colliding_agents_that_ran_all_ten_qps": int(sum(1 for c_ in colliding for a_ in c_["agents"] if a_["sqp_iterations"] >= 10)),
                       "note": "rectangle/rectangle and disc/rectangle checks of the final trajectories (csdo_validate); "
                               "the stand-in's coarse paths (worlds the search does not solve) are not collision-free"}
 

@@ -30,7 +30,7 @@
 #include "csdo_device_types.h"
 #include "dsqp_layout.h"
 
-// experiment switches of round 5 (each measured with old and new library interleaved on one box, scripts/gpu_ab.sh)
+// experiment switches of round 5 (each measured with old and new library interleaved on one box, scripts/gpu_run.sh ab:)
 #if !defined(CSDO_ABSORB_BY_NEIGHBOUR)
 #define CSDO_ABSORB_BY_NEIGHBOUR 1   // mode 0 factorisation: the eliminated node's lane copies the survivor's new coupling out of LDS
 #endif

@@ -250,10 +250,12 @@ def interpolate_states(solutions, frames_per_move):
     return out
 
 
-def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0, frames_per_move=None) -> ValidationReport:
+def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0, frames_per_move=None, participants=None) -> ValidationReport:
     """solutions [Na][Nt][>=3]; obstacles [n][3] = x, y, r.  `margin` inflates every vehicle rectangle on all sides.
     frames_per_move = None: the Nt states as they are.  An integer S >= 1: the frames of the authors' animation
-    (interpolate_states: S frames per move, scripts/visualize.py:219-247); every index in the report is then a frame."""
+    (interpolate_states: S frames per move, scripts/visualize.py:219-247); every index in the report is then a frame.
+    participants: a dict that receives WHO collides - "vehicle_pairs": [(i, j, frames in collision)], "obstacle_agents":
+    [(agent, frames in collision)] - beside the counts of the report."""
     sol = np.asarray(solutions, dtype=np.float64)
     if frames_per_move is not None:
         sol = interpolate_states(sol, frames_per_move)
@@ -282,6 +284,8 @@ def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0, f
         if veh_hits:
             p, t = np.argwhere(ov)[np.argmin(np.argwhere(ov)[:, 1])]
             first_v = (int(t), int(iu[0][p]), int(iu[1][p]))
+        if participants is not None:
+            participants["vehicle_pairs"] = [(int(iu[0][p_]), int(iu[1][p_]), int(ov[p_].sum())) for p_ in np.nonzero(ov.any(axis=1))[0]]
     # ---- circle / rectangle: distance from the disc centre to the rectangle in the rectangle's frame
     obs_hits, first_o, clearance = 0, None, np.inf
     if obstacles is not None and len(obstacles):
@@ -299,6 +303,8 @@ def validate(solutions, veh, obstacles=None, dimx=None, dimy=None, margin=0.0, f
             idx = np.argwhere(hit)
             a, t, o = idx[np.argmin(idx[:, 1])]
             first_o = (int(t), int(a), int(o))
+        if participants is not None:
+            participants["obstacle_agents"] = [(int(a_), int(hit[a_].any(axis=1).sum())) for a_ in np.nonzero(hit.any(axis=(1, 2)))[0]]
     out = 0
     if dimx is not None and dimy is not None:
         corners = [c + sx * hl * u + sy * hw * n for sx in (-1, 1) for sy in (-1, 1)]

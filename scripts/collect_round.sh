@@ -1,5 +1,5 @@
 #!/bin/bash
-# After scripts/gpu_full.sh <tag> (+ phase profiles, stand-in benches): copy what is judged from gpurun_out/ into profiles/.
+# After scripts/gpu_run.sh <tag> tests round profile:<workload>... (+ phase profiles, stand-in benches): copy what is judged from gpurun_out/ into profiles/.
 #   usage: collect_round.sh <tag>
 set -u
 cd "$(dirname "$0")/.."
@@ -18,8 +18,8 @@ done
 [ -f gpurun_out/$TAG/phases_map50.txt ] && cp gpurun_out/$TAG/phases_map50.txt profiles/${TAG}_phase_profile_map50.txt
 [ -f gpurun_out/$TAG/phases_room50_long.txt ] && cp gpurun_out/$TAG/phases_room50_long.txt profiles/${TAG}_phase_profile_room50_long_horizons.txt
 [ -f gpurun_out/$TAG/group_times_room50.txt ] && grep -v amdgpu gpurun_out/$TAG/group_times_room50.txt > profiles/${TAG}_group_times_room50.txt
-grep -E "passed|failed" gpurun_out/$TAG/pytest_gpu.log | tail -1 > profiles/${TAG}_pytest_gpu_summary.txt
-grep -E "^PASSED|^FAILED" gpurun_out/$TAG/pytest_gpu.log >> profiles/${TAG}_pytest_gpu_summary.txt
+grep -E "passed|failed" gpurun_out/$TAG/pytest.log | tail -1 > profiles/${TAG}_pytest_gpu_summary.txt
+grep -E "^PASSED|^FAILED" gpurun_out/$TAG/pytest.log >> profiles/${TAG}_pytest_gpu_summary.txt
 for w in map100 map50; do [ -f gpurun_out/${TAG}s/bench_$w.json ] && tail -1 gpurun_out/${TAG}s/bench_$w.json > profiles/${TAG}_standin_bench_$w.json; done
 python - <<PY
 import json

@@ -8,6 +8,9 @@
 #     single:<lib>[,<lib>...]               one 50-agent instance alone (scripts/single_instance_times.py)
 #     phases:<workload>[:<lib>]             in-kernel phase profile (prof build or the library given)
 #     refined:<workload>[,...]              bench lines with csdo_qp_parm::solve_refinement = 1
+#     smoke                                 __graft_entry__.smoke()
+#     round                                 the round's record: all bench lines, phase profiles, sweep, ... (then scripts/collect_round.sh)
+#     boxes                                 safe-box ablation builds
 #     profile:<workload>                    rocprofv3 kernel trace + PMC passes (scripts/profile_round.sh), summaries into profiles/ by collect
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -57,6 +60,27 @@ PY
       for w in ${arg//,/ }; do
         timeout 600 python bench.py --workload $w --solve-refinement --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_refined_$w.json 2> $O/bench_refined_$w.err; echo "bench refined $w rc=$?"
         python -c "import json,sys; d=json.load(open(sys.argv[1])); print('  refined %s: %.2f M it/s  %.2f ms/step  single %.2f ms' % (sys.argv[2], d['value']/1e6, d['ms_per_step'], d['single_instance']['do_phase_ms']['solve_kernel']))" $O/bench_refined_$w.json $w
+      done ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log ;;
+    round)     # everything a round's record needs beside the tests: host info, all five bench lines, the one-rank RCCL line, phase
+               # profiles, streamed chunkings, the authors' sweep, single instances, launch-group times (collect: scripts/collect_round.sh <tag>)
+      python -c "import os; print('cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))" > $O/host_info.txt 2>&1
+      for w in map100 map50 synth1024 room50 agents100; do
+        timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w rc=$?"
+      done
+      timeout 600 python bench.py --force-dist --no-cpu-baseline > $O/bench_map100_force_dist.json 2> $O/bench_map100_force_dist.err; echo "bench force-dist rc=$?"
+      timeout 600 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 map100 > $O/phases_map100.txt 2>&1
+      timeout 600 python scripts/profile_phases_sum.py 0,2,3,4,5,6,7,9 map50 > $O/phases_map50.txt 2>&1
+      timeout 600 python scripts/profile_phases_sum.py 1,2 room50 > $O/phases_room50_long.txt 2>&1
+      timeout 600 python scripts/stream_fractions.py map100 "0.08,0.27,0.65" > $O/stream_map100.txt 2>&1
+      timeout 900 python scripts/authors_sweep.py $O/authors_sweep.json > $O/authors_sweep.log 2>&1
+      timeout 300 python scripts/single_instance_times.py > $O/single_instance_times.txt 2>&1
+      timeout 300 python scripts/group_times.py room50 > $O/group_times_room50.txt 2>&1 ;;
+    boxes)     # what the pieces of a safe box cost: phase-timer builds that do one piece twice (scripts/build_prof_ablation.sh)
+      for t in "" _box2x_ALL _box2x_PASSES _box2x_REPLAY _box2x_CULL; do
+        CSDO_PROF_LIB=libcsdo_hip_prof$t.so timeout 600 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 map100 > $O/phases$t.txt 2>&1
+        echo "prof$t: $(sed -n 1p $O/phases$t.txt | cut -c1-80)"; grep -m1 "cycles per SQP iteration: corridor" $O/phases$t.txt
       done ;;
     *) echo "unknown step $step" ;;
   esac

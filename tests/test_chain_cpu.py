@@ -62,14 +62,14 @@ def test_committed_outlier_list_is_what_the_lane_serial_build_gives(emu, oracle,
     assert set(found) == set(listed), (sorted(set(found) - set(listed)), sorted(set(listed) - set(found)))
     for wa, (dv, sm) in found.items():
         assert abs(dv - listed[wa]["d"]) <= 1e-12 + 1e-9 * listed[wa]["d"] and sm == listed[wa]["same_counts"], (wa, dv, listed[wa])
-    # what the sets as a whole look like (committed by scripts/chain_parity.py, full sets): the product is beyond 1e-4 of the oracle
-    # on at most 1.6 x as many agents as the oracle is of its own FMA build (+ 3), nearly all of them agents on which one of the
-    # oracle's own alternative builds also moves by more than 1e-6
-    n = fx["outlier_counts"]
-    assert n["product_vs_oracle"] <= 1.6 * n["oracle_fma_vs_oracle"] + 3, n
+    # what the sets as a whole look like (committed by scripts/chain_parity.py, full sets).  Round 5 held the product's count against the
+    # oracle's FMA build by a fitted bar (1.6 x + 3); round 6 holds it against the exact-arithmetic ARBITER instead
+    # (tests/test_refinement.py::test_committed_totals_against_the_arbiter: product_refined <= oracle, product <= 1.5 x oracle + 2, both
+    # counted against oracle_q).  Kept here: nearly all of the product's outliers against the ORACLE are agents on which one of the
+    # oracle's own alternative builds also moves by more than 1e-6, or which the arbiter itself puts beyond 1e-4 of the oracle.
     sens = {(w, a) for w, a, _ in fx["oracle_sensitive"]}
     insensitive = [(o["world"], o["agent"]) for o in fx["outliers"]
-                   if (o["world"], o["agent"]) not in sens and not o.get("d_oracle_xm", 0.0) > 1e-6]
+                   if (o["world"], o["agent"]) not in sens and not o.get("d_oracle_xm", 0.0) > 1e-6 and not o.get("d_oracle_q", 0.0) > 1e-6]
     assert len(insensitive) <= 0.2 * len(fx["outliers"]) + 1, insensitive
 
 

@@ -121,9 +121,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
   __shared__ int next_in_queue;
   static_assert(SPLIT, "one thread per timestep playing both roles is only built lane-serially (tests/emu)");
   if (threadIdx.x < BLOCK / 2) {        // row waves
-#if defined(CSDO_PRIO_ROW)
-    __builtin_amdgcn_s_setprio(CSDO_PRIO_ROW);   // experiment: the row waves' instructions first where both roles have work (the update)
-#endif
     for (;;) {
       if (threadIdx.x == 0) next_in_queue = atomicAdd(queue, 1);
       __syncthreads();

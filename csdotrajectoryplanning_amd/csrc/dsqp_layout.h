@@ -19,9 +19,6 @@ constexpr int TAIL_NODES_BIG = 12, TAIL_N_BIG = 6 * TAIL_NODES_BIG;
 //  costs 20 k cycles per SQP iteration and the larger inverse takes the LDS that cached the planes' coefficients: map100 53.2 -> 54.0 ms,
 //  one instance alone 8.32 -> 8.19 ms; profiles/r06_phase_profile_map100_folded_tail.txt)
 
-#if !defined(CSDO_SINV_LDS)
-#define CSDO_SINV_LDS 1   // 1: the pivot inverse of a node (21 doubles, read once per iteration in the w pass) sits in LDS; 0: in the workspace
-#endif
 #if !defined(CSDO_ER_REG)
 #define CSDO_ER_REG 34   // round 5 (after the spills of the cold phases went: no reload in the levels at 32, 34, 36 any more), map100 / synth1024 ms per step: 30: 56.90 / 38.14, 32: 56.70 / 37.95, 34: 55.99 / 37.29, 36: 56.39 / 37.59; pair-split solve of round 4: 12: 73.4, 18: 71.5, 24: 66.4, 30: 65.8, 36: 71.9 (32 and 34 put scratch reloads into the levels then); one-lane form of round 3: 20: 83.1, 24: 79.9, 32: 80.2, 36: 81.0
 #endif
@@ -39,7 +36,7 @@ constexpr int ER_REG2 = CSDO_ER_REG2, FX_ER2 = 36 - ER_REG2;
 // lane-major leading dimensions (doubles per lane) of the LDS arrays.  All are 2 * odd: 16-byte aligned lanes, and the
 // ds_read_b128 / ds_write_b128 of 16 consecutive lanes (also of lanes a power of two apart) fall into 16 different
 // 4-bank groups - conflict free.  (12 doubles, the former reduction stride, is 2-way conflicting.)
-constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + (CSDO_SINV_LDS ? 21 : 0) + 1) / 2) | 1),
+constexpr int LD_vec = 6, LD_pl = 6, LD_pr = 6, LD_rhs = 6, LD_carry = 6, LD_carry2 = 6, LD_red = 14, LD_lohi = 22, LD_fx = 2 * (((FX_ER + 21 + 1) / 2) | 1),
               // the block's per-timestep arrays (vec .. fx) double as the factorisation's exchange columns, 78 fields x stride
               LD_block = (24 + LD_lohi + LD_fx) > 78 ? (24 + LD_lohi + LD_fx) : 78,
               LD_fx2 = 34, LD_block2 = 18 + LD_fx2,   // mode 2: vec, pr (= rhs), carry (whose two spare doubles per lane hold the block's last two entries) + fx

@@ -30,37 +30,18 @@
 #include "csdo_device_types.h"
 #include "dsqp_layout.h"
 
-// experiment switches of round 5 (each measured with old and new library interleaved on one box, scripts/gpu_run.sh ab:)
-#if !defined(CSDO_ABSORB_BY_NEIGHBOUR)
-#define CSDO_ABSORB_BY_NEIGHBOUR 1   // mode 0 factorisation: the eliminated node's lane copies the survivor's new coupling out of LDS
-#endif
-#if !defined(CSDO_TAIL_GROUPS)
-#define CSDO_TAIL_GROUPS 1           // the dense tail is inverted with sets of mutually uncoupled pivot blocks ({1,3,5}, {0,4}, {2}): three serial 6x6
-#endif                               // inverses instead of six; another elimination order = other last bits than round 4's results
-#if !defined(CSDO_RUIZ_PARK)
-#define CSDO_RUIZ_PARK 1             // nine of the row lane's coefficients wait in LDS between the equilibration's passes
-#endif
-#if !defined(CSDO_ONCE_LOOPS)
-#define CSDO_ONCE_LOOPS 2            // one-trip loops around the two level-1 steps of the solve (round 4: outside any loop of the iteration the level-1 block was what the allocator
-                                     // spilled - still true: 18 reloads per solve without them); 2: as do-while - as `for` loops they cost 42 register copies per iteration (the step's
-                                     // results merged with "what was there before" on a zero-trip path that does not exist): map100 55.91 -> 55.35 ms, synth1024 37.42 -> 37.05
-#endif
-#if !defined(CSDO_LANE_MODE_DEVICE)   /* (the lane-serial build has no register allocation to steer: a step's lanes-blocks are several statements there) */
+// (The experiment switches of rounds 3 - 5 - CSDO_ABSORB_BY_NEIGHBOUR, CSDO_TAIL_GROUPS, CSDO_RUIZ_PARK, CSDO_ONCE_LOOPS, CSDO_TS_LDS, CSDO_TID_*,
+//  CSDO_TRIG_CALL, CSDO_BOX_CALL, CSDO_GROW_PACKED, CSDO_SINV_LDS, CSDO_PRIO_ROW - are gone: the winning branch is the code, what lost is
+//  recorded with its numbers in DESIGN section 3 and as patches / notes under scripts/experiments/.)
+// One-trip loops around the two level-1 steps of the pair-split solve: outside any loop of the iteration the level-1 block is what the
+// register allocator spills (18 reloads per solve without them); as do-while - no zero-trip path, so what the step defines needs no merge
+// with "what was there before" (as `for` loops: 42 register copies per iteration).  The lane-serial build has no allocation to steer.
+#if !defined(CSDO_LANE_MODE_DEVICE)
 #define CSDO_ONCE_LOOP
 #define CSDO_ONCE_END
-#elif CSDO_ONCE_LOOPS == 1
-#define CSDO_ONCE_LOOP for (int once_ = 0; once_ < csdo_opaque_s(1); ++once_)
-#define CSDO_ONCE_END
-#elif CSDO_ONCE_LOOPS == 2   /* the same as a do-while: no zero-trip path, so what the step defines needs no merge with what was there before */
+#else
 #define CSDO_ONCE_LOOP { int once_ = 0; do
 #define CSDO_ONCE_END while (++once_ < csdo_opaque_s(1)); }
-#else
-#define CSDO_ONCE_LOOP
-#define CSDO_ONCE_END
-#endif
-#if !defined(CSDO_TS_LDS)
-#define CSDO_TS_LDS 0                // modes 0, 1: a timestep's plane range in LDS (carry's spare doubles) instead of lane state: the rhs assembly loses its
-                                     // two scratch reloads and the step gets SLOWER (map100 57.99 -> 58.63 ms): the reloads were hidden, the LDS reads are not
 #endif
 
 #if defined(CSDO_LANE_MODE_DEVICE)
@@ -104,28 +85,13 @@ __device__ __forceinline__ double csdo_one_if(const bool c, const double d) {
 // Nt - before its first useful access (six per Ruiz pass, hundreds per SQP iteration).  CSDO_TID recomputes it where it is asked for
 // (volatile: neither hoisted nor kept across blocks - the same job the empty asm of csdo_opaque did for the old form);
 // CSDO_TID_HOT (the blocks of the ADMM iteration) is the same.
-#if !defined(CSDO_TID_MBCNT)
-#define CSDO_TID_MBCNT 1
-#endif
-#if CSDO_TID_MBCNT
 __device__ __forceinline__ int csdo_lane_id() {
   int l;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
   return l;
 }
 #define CSDO_TID (sh.wave0 + csdo_lane_id())
-#if !defined(CSDO_TID_HOT_VOLATILE)
-#define CSDO_TID_HOT_VOLATILE 0   /* 1: recomputed in the iteration's blocks too - no scratch reload at the head of the update, and slower (57.99 -> 58.42 ms) */
-#endif
-#if CSDO_TID_HOT_VOLATILE
-#define CSDO_TID_HOT CSDO_TID   /* (as a plain expression it was computed once, spilled, and reloaded - with a full wait - at the head of every update) */
-#else
 #define CSDO_TID_HOT (sh.wave0 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
-#endif
-#else
-#define CSDO_TID csdo_opaque((int)threadIdx.x)
-#define CSDO_TID_HOT ((int)threadIdx.x)
-#endif
 #define CSDO_LANES(t) if constexpr (ROLE != ROLE_SOLVER) if (const int t = CSDO_TID; t < Nt)
 // ROLE_BOTH on the device: one thread per timestep plays both roles (256 threads, 512 registers per lane)
 #define CSDO_SOLVER_BASE ((ROLE == ROLE_BOTH) ? 0 : (int)(blockDim.x >> 1))
@@ -257,16 +223,13 @@ inline int csdo_dpp_src(const int ctrl, const int t, const int n_lanes) {
 
 namespace csdo {
 
-// The program's call sites of the shared trigonometry.  On the device they are REAL CALLS (CSDO_TRIG_CALL, default 1): every
+// The program's call sites of the shared trigonometry.  On the device they are REAL CALLS: every
 // inlined copy of a cold piece moves the register allocation of the ADMM loop - inlined at their eight
 // sites these functions put six scratch reloads into every solve of the 512-thread class and the map100 step went from 60.2
 // to 69.4 ms; as calls (doubles in, doubles out: nothing lives in memory across them) the program has fewer spills than before
 // (VGPR dwords 429 -> 309, SGPR 885 -> 647) and the step is 59.8 ms.  Same bits either way.
 struct SinCos { double s, c; };
-#if !defined(CSDO_TRIG_CALL)
-#define CSDO_TRIG_CALL 1
-#endif
-#if CSDO_TRIG_CALL && defined(CSDO_LANE_MODE_DEVICE)
+#if defined(CSDO_LANE_MODE_DEVICE)
 #define CSDO_TRIG_FN CSDO_NOINLINE
 #else
 #define CSDO_TRIG_FN CSDO_FN
@@ -774,9 +737,6 @@ CSDO_FN bool box_valid(const BoxD& b, const double* obs, int n_obs, double dimx,
 // E comes from a quotient; the sequential sums differ from c0 + n * 0.1 by < 1e-12, so the quotient is only trusted when it is
 // further than 1e-7 steps from an integer; otherwise E is found by replaying the additions against the exact inequality.
 // Results are bit-identical to the trial-by-trial walk (tests/test_boxes_serial.py against the oracle's, random maps).
-#if defined(CSDO_GROW_STATS)
-inline long csdo_grow_stats[2] = {0, 0};
-#endif
 constexpr int grow_limit_steps() {   // accepted steps until len >= l_limit, len summed as the reference does: 101
   double len = 0.0;
   int n = 0;
@@ -803,9 +763,6 @@ CSDO_FN int first_step(const int d, const double xc, const double yc, const doub
   const double fl = floor(g);
   const double frac = g - fl;
   if (frac < 1e-7 || frac > 1.0 - 1e-7) {         // too close to call from the quotient: walk the additions
-#if defined(CSDO_GROW_STATS)
-    csdo_grow_stats[1]++;
-#endif
     double c = c0;
     int n = 0;
     while (n < GROW_NEVER && !(up ? (o < (c + infl)) : ((c - infl) < o))) {
@@ -826,10 +783,6 @@ struct BoxCache {
   unsigned* base;
   int stride, cap;
 };
-#if !defined(CSDO_GROW_PACKED)
-#define CSDO_GROW_PACKED 1   // 1: the stop events decoded from the packed word (below); 0: round 3's side-by-side loops
-#endif
-#if CSDO_GROW_PACKED
 // first_step with the side known at compile time (no selects on d; the four of an obstacle are straight-line code)
 template <int D>
 CSDO_FN int first_step_of(const double xc, const double yc, const double ox, const double oy, const double infl) {
@@ -841,9 +794,6 @@ CSDO_FN int first_step_of(const double xc, const double yc, const double ox, con
   const double fl = floor(g);
   const double frac = g - fl;
   if (frac < 1e-7 || frac > 1.0 - 1e-7) {
-#if defined(CSDO_GROW_STATS)
-    csdo_grow_stats[1]++;
-#endif
     const double step = up ? 0.1 : -0.1;
     double c = c0;
     int n = 0;
@@ -897,9 +847,6 @@ CSDO_FN double add_steps(double c, const double step, int n) {
 CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
                       BoxD& res, const BoxCache& ec, const ObsMask& M) {
   const double ds = 0.1;
-#if defined(CSDO_GROW_STATS)
-  csdo_grow_stats[0]++;
-#endif
   // round in which a side's trial fails for a reason of its own: the map border, or the step after the last allowed one
   int stop0 = 1, stop1 = 1, stop2 = 1, stop3 = 1;
   {
@@ -999,136 +946,6 @@ CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double
   res = box;
   return (st0 + st1 + st2 + st3) > 0;
 }
-#else
-CSDO_FN bool grow_box(double xc, double yc, const double* obs, int n_obs, double dimx, double dimy, double rv,
-                      BoxD& res, const BoxCache& ec, const ObsMask& M) {
-  const double ds = 0.1;
-#if defined(CSDO_GROW_STATS)
-  csdo_grow_stats[0]++;
-#endif
-  // round in which a side's trial fails for a reason of its own: the map border, or the step after the last allowed one
-  int stop0 = 1, stop1 = 1, stop2 = 1, stop3 = 1;
-  {
-    const double x_hi = dimx - rv, y_hi = dimy - rv;
-    if (!(xc < rv || xc > x_hi || yc < rv || yc > y_hi)) {
-#if defined(CSDO_LANE_MODE_DEVICE)
-#pragma nounroll
-#endif
-      for (int d = 0; d < 4; ++d) {
-        int v = first_step(d, xc, yc, (d == 1) ? rv : x_hi, (d == 2) ? rv : y_hi, 0.0);
-        v = v < 1 ? 1 : (v > GROW_LIMIT + 1 ? GROW_LIMIT + 1 : v);
-        if (d == 0) stop0 = v;
-        if (d == 1) stop1 = v;
-        if (d == 2) stop2 = v;
-        if (d == 3) stop3 = v;
-      }
-    }
-  }
-  int st0 = 0, st1 = 0, st2 = 0, st3 = 0;   // accepted steps of the sides that have stopped
-  unsigned moving = 0xFu;
-  bool seed_inside = false;
-#if defined(CSDO_ABL_BOX2X_PASSES)   // diagnostic: the passes twice, same results (what they cost = the difference)
-  for (int rep_ = 0; rep_ < csdo_opaque_s(2); ++rep_) {
-  st0 = st1 = st2 = st3 = 0; moving = 0xFu; seed_inside = false;
-#endif
-  for (int pass = 0; pass < 4 && !seed_inside; ++pass) {
-    // earliest trial that fails, key = 4 * round + side
-    int best = 4 * (GROW_LIMIT + 2);
-    if (moving & 1u) best = 4 * stop0 + 0 < best ? 4 * stop0 + 0 : best;
-    if (moving & 2u) best = 4 * stop1 + 1 < best ? 4 * stop1 + 1 : best;
-    if (moving & 4u) best = 4 * stop2 + 2 < best ? 4 * stop2 + 2 : best;
-    if (moving & 8u) best = 4 * stop3 + 3 < best ? 4 * stop3 + 3 : best;
-    unsigned long long m0 = M.m[0], m1 = M.m[1], m2 = M.m[2], m3 = M.m[3];
-    int k_tail = OBS_MASK_CAP;
-    int j_ = 0;   // position of the obstacle in this (deterministic) order: its slot in the cache
-    while ((m0 | m1 | m2 | m3) != 0ull || k_tail < n_obs) {
-      int k;
-      if (m0) {
-        k = ctz64(m0);
-        m0 &= m0 - 1;
-      } else if (m1) {
-        k = 64 + ctz64(m1);
-        m1 &= m1 - 1;
-      } else if (m2) {
-        k = 128 + ctz64(m2);
-        m2 &= m2 - 1;
-      } else if (m3) {
-        k = 192 + ctz64(m3);
-        m3 &= m3 - 1;
-      } else {
-        k = k_tail++;
-      }
-      // the stopped sides must have their inequality true where they stopped; among the moving ones the obstacle is entered
-      // in round mx by the last side that attains it
-      bool live = true;
-      int mx = 0, last = 0;
-      unsigned packed = 0u;
-      const bool cached = j_ < ec.cap;
-      if (cached && pass > 0) {
-        packed = ec.base[(size_t)j_ * (size_t)ec.stride];
-      } else {
-        const double ox = obs[k], oy = obs[n_obs + k], infl = obs[2 * n_obs + k];   // (staged as r_obs + rv)
-#if defined(CSDO_LANE_MODE_DEVICE)
-#pragma nounroll
-#endif
-        for (int d = 0; d < 4; ++d) packed |= (unsigned)first_step(d, xc, yc, ox, oy, infl) << (8 * d);
-        if (cached) ec.base[(size_t)j_ * (size_t)ec.stride] = packed;
-      }
-      ++j_;
-#if defined(CSDO_LANE_MODE_DEVICE)
-#pragma nounroll
-#endif
-      for (int d = 0; d < 4; ++d) {
-        const int e = (int)((packed >> (8 * d)) & 0xffu);
-        const int stopped_at = (d == 0) ? st0 : (d == 1) ? st1 : (d == 2) ? st2 : st3;
-        if (moving & (1u << d)) {
-          if (e >= mx) {
-            mx = e;
-            last = d;
-          }
-        } else if (e > stopped_at) {
-          live = false;
-        }
-      }
-      if (live && mx < 1) seed_inside = true;   // every inequality holds at the seed: no trial can succeed
-      const int key = 4 * mx + last;
-      if (live && key < best) best = key;
-    }
-    const int side = best & 3, round = best >> 2;
-    if (side == 0) st0 = round - 1;
-    if (side == 1) st1 = round - 1;
-    if (side == 2) st2 = round - 1;
-    if (side == 3) st3 = round - 1;
-    moving &= ~(1u << side);
-  }
-#if defined(CSDO_ABL_BOX2X_PASSES)
-  }
-#endif
-  if (seed_inside) {   // (only ever found in the first pass: later, an obstacle that holds the box would have stopped a side)
-    res = BoxD{xc, yc, xc, yc};
-    return false;
-  }
-  // replay: the coordinates are the same sums as in the reference's walk
-  // (a loop per side, as long as that side's step count: one loop over all GROW_LIMIT steps with four tests and selects per step
-  //  was 23 k cycles per SQP iteration for 4 x 101 additions)
-  BoxD box{xc, yc, xc, yc};
-#if defined(CSDO_ABL_BOX2X_REPLAY)
-  for (int rep_ = 0; rep_ < csdo_opaque_s(2); ++rep_) {
-  box = BoxD{xc, yc, xc, yc};
-#endif
-  const int lim0 = st0 < GROW_LIMIT ? st0 : GROW_LIMIT, lim1 = st1 < GROW_LIMIT ? st1 : GROW_LIMIT,
-            lim2 = st2 < GROW_LIMIT ? st2 : GROW_LIMIT, lim3 = st3 < GROW_LIMIT ? st3 : GROW_LIMIT;
-  for (int n = 0; n < lim0; ++n) box.y_max += ds;
-  for (int n = 0; n < lim1; ++n) box.x_min -= ds;
-  for (int n = 0; n < lim2; ++n) box.y_min -= ds;
-  for (int n = 0; n < lim3; ++n) box.x_max += ds;
-#if defined(CSDO_ABL_BOX2X_REPLAY)
-  }
-#endif
-  res = box;
-  return (st0 + st1 + st2 + st3) > 0;
-}
-#endif
 
 // generateBox, corridor.cc:124-159.  Returns bit0 = success, bits1-2 = initial status (0 legal, 1 out of map,
 // 2 inside an inflated obstacle).  First colliding obstacle = lowest input index (documented deviation from the
@@ -1204,41 +1021,9 @@ CSDO_FN int make_box(double x, double y, const double* obs, int n_obs, double di
   return (success ? 1 : 0) | (initial << 1);
 }
 
-// A box at one call site of the agent program.  CSDO_BOX_CALL (device build only): a REAL call - the box code (cull, the four stop
-// events, the replay, the repair of a point inside an obstacle) is the largest cold piece of the program and was inlined four
-// times, twice per role; as a call there is one copy, and the LDS arrays it reads (the obstacle list, the cache of step counts)
-// are rebuilt inside the callee from their offsets in the workgroup's dynamic LDS, so that they stay ds_* accesses (an LDS
-// pointer passed through an argument has lost its address space).  Same bits either way.  CSDO_BOX_CALL is a mask: 1 = the row
-// role's sites (front discs), 2 = the solver role's (rear discs).
-struct BoxOut {
-  double x_min, y_min, x_max, y_max;
-  int status;
-};
-#if !defined(CSDO_BOX_CALL)
-#define CSDO_BOX_CALL 0
-#endif
-#if CSDO_BOX_CALL && defined(CSDO_LANE_MODE_DEVICE)
-__device__ __noinline__ BoxOut make_box_call(const double x, const double y, const int obs_off, const int n_obs, const double dimx,
-                                             const double dimy, const double rv, const int cache_off, const int cache_stride,
-                                             const int cache_cap) {
-  extern __shared__ __align__(16) double csdo_lds_base[];
-  BoxD b{0, 0, 0, 0};
-  const BoxCache ec{(unsigned*)csdo_lds_base + cache_off, cache_stride, cache_cap};
-  const int st = make_box(x, y, csdo_lds_base + obs_off, n_obs, dimx, dimy, rv, b, ec);
-  return BoxOut{b.x_min, b.y_min, b.x_max, b.y_max, st};
-}
-template <bool CALL>
-CSDO_FN int box_at(const double x, const double y, const double* obs, const int n_obs, const double dimx, const double dimy,
-                   const double rv, BoxD& res, const BoxCache& ec) {
-  if constexpr (!CALL) return make_box(x, y, obs, n_obs, dimx, dimy, rv, res, ec);
-  extern __shared__ __align__(16) double csdo_lds_base[];
-  const int obs_off = uniform_i32((int)(obs - (const double*)csdo_lds_base));
-  const BoxOut o = make_box_call(x, y, obs_off, n_obs, dimx, dimy, rv, (int)(ec.base - (unsigned*)csdo_lds_base), ec.stride, ec.cap);
-  res = BoxD{o.x_min, o.y_min, o.x_max, o.y_max};
-  return o.status;
-}
-#else
-template <bool CALL>
+// A box at one call site of the agent program (inlined, four sites: as a REAL call - one copy of the largest cold piece, its LDS arrays
+// rebuilt in the callee from their offsets - it was neutral on map100, -0.4 % on map50 and +2 % on room50 from the row role only, and
+// put six scratch reloads into the solve from both roles: round 5).
 CSDO_FN int box_at(const double x, const double y, const double* obs, const int n_obs, const double dimx, const double dimy,
                    const double rv, BoxD& res, const BoxCache& ec) {
 #if defined(CSDO_ABL_BOX2X_ALL)   // diagnostic: every box twice
@@ -1246,7 +1031,6 @@ CSDO_FN int box_at(const double x, const double y, const double* obs, const int 
 #endif
   return make_box(x, y, obs, n_obs, dimx, dimy, rv, res, ec);
 }
-#endif
 
 // =========================================================================================================
 // 6x6 dense helpers (all indices compile-time so everything stays in registers)

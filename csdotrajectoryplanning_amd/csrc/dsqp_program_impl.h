@@ -17,7 +17,7 @@ namespace csdo {
 // everything from the workspace for long horizons
 // (MODE 2: the lean modes' layout - nothing of the factor in registers - with all of F_r in LDS, 36 doubles per timestep)
 #define ER(k, t) FE(36 + (k), t)   /* one-lane form (mode 3): F_r of node t from the workspace */
-#define SINV(k, t) ((MODE >= 1 || !CSDO_SINV_LDS) ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
+#define SINV(k, t) ((MODE >= 1) ? WS(W_SINV + (k), t) : SH(fx, FX_ER + (k), t))
 // set-up stage scratch, field-major over the ADMM block's exchange arrays (see "assemble the QP")
 #define SU(k, t) sh.vec[(size_t)(k) * (size_t)csdo_opaque_s(sh.stride) + (unsigned)(t)]
 // (the stride passes through an empty asm at every use: the per-slot base addresses - some sixty 64-bit scalars - are then formed
@@ -537,7 +537,7 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
     CSDO_SYNC();
     CSDO_FPHASE(19);
-    if constexpr (MODE == 0 && CSDO_ABSORB_BY_NEIGHBOUR) {
+    if constexpr (MODE == 0) {
       // The eliminated nodes' lanes (idle otherwise) move what sits in LDS columns to its place in the workspace: their own
       // F_r = V', and - for the surviving node on their left - the coupling to its new right neighbour (fields 42..77 of THAT node's
       // column).  The survivor's lane did that copy itself, in the middle of its work on the diagonal block: five entries of the
@@ -556,26 +556,13 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
       }
     }
     CSDO_SLANES(t) {  // remaining nodes absorb the Schur complements (and, but for mode 0, take the coupling to their new right neighbour)
-      if constexpr (MODE == 0 && !CSDO_ABSORB_BY_NEIGHBOUR) {   // (beside them, the eliminated nodes move F_r = V' from their LDS column to its place)
-        if ((t & m2) == h && (t + h) < Nt) CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { PF_R(c * 6 + r, t) = XC(r * 6 + c, t); }); });
-      }
       if ((t & m2) == 0) {
         double A[21];
         CSDO_FOR(k, 21, { A[k] = FA(k, t); });
         if constexpr (MODE == 0) {   // delivered into this node's own column (see the elimination above)
           if (t >= h) CSDO_FOR(k, 21, { A[k] -= XC(k, t); });
           if ((t + h) < Nt) {
-            CSDO_FOR(k, 21, { A[k] -= XC(21 + k, t); });
-            if constexpr (!CSDO_ABSORB_BY_NEIGHBOUR) {
-              const bool has_rr = (t + 2 * h) < Nt;
-              // (one branch and the 36 reads in flight: as `has_rr ? read : 0.0` per element it was a branch, an LDS round trip and - for
-              //  the zero, a spilled constant - a scratch reload in front of every one of the 36 stores)
-              if (has_rr) {
-                CSDO_FOR(k, 36, { FR(k, t) = XC(42 + k, t); });
-              } else {
-                CSDO_FOR(k, 36, { FR(k, t) = 0.0; });
-              }
-            }
+            CSDO_FOR(k, 21, { A[k] -= XC(21 + k, t); });   // (the coupling to the new right neighbour: copied by the eliminated node's lane, above)
           }
         } else {
           if (t >= h) CSDO_FOR(k, 21, { A[k] -= SX(21 + k, t - h); });
@@ -630,7 +617,6 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
   }
   CSDO_SYNC();
-#if CSDO_TAIL_GROUPS
   // In-place inversion by BLOCK Gauss-Jordan with SETS of pivot blocks.  The tail system is block tridiagonal (<= 6 nodes of 6), so
   // its odd nodes are mutually uncoupled, and once they are eliminated so are nodes 0 and 4 of the remaining chain 0 - 2 - 4: three
   // pivot sets {1, 3, 5}, {0, 4}, {2} (the members that exist) instead of six pivots one after the other - the chain of serial 6x6
@@ -717,79 +703,6 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
     }
     CSDO_SYNC();
   }
-#else
-  static_assert(!BIGT, "a tail of more than six nodes needs the pivot sets");
-  // In-place inversion by BLOCK Gauss-Jordan, one 6x6 pivot block per tail node (the pivot blocks of an SPD matrix are SPD:
-  // no pivoting).  Scalar Gauss-Jordan was 36 pivots x 2 barriers of mostly latency (77 k cycles per factorisation); this is
-  // <= 6 block pivots x 3 barriers.  For pivot block P (rows / columns 6p .. 6p+5) and everything else R:
-  //   A[P,R] <- Pinv A[P,R];   A[R,R] <- A[R,R] - A[R,P] A[P,R];   A[R,P] <- -A[R,P] Pinv;   A[P,P] <- Pinv
-  // Pinv of the NEXT pivot is computed by one lane while the column block of the current one is finished.
-  double* const pinv = sh.vec;     // 36 doubles of scratch: the exchange vectors are dead during the factorisation
-  const int n_piv = n_tail / 6;
-  auto pivot_inverse = [&](const int p) __attribute__((always_inline)) {   // one lane: packed lower triangle -> full 6x6 inverse
-    double Ain[21], Pin[21];
-    CSDO_FOR(r, 6, { CSDO_FOR(c, r + 1, { Ain[sym(r, c)] = TINV(6 * p + c, 6 * p + r); }); });
-    spd_inverse6(Ain, Pin);
-    CSDO_FOR(r, 6, { CSDO_FOR(c, 6, { pinv[r * 6 + c] = Pin[sym(r, c)]; }); });
-  };
-  CSDO_TLANES(t) {
-    if (t == 0) pivot_inverse(0);
-  }
-  CSDO_SYNC();
-  for (int p = 0; p < n_piv; ++p) {
-    const int p0 = 6 * p;
-    CSDO_STHREADS(l, nthr) {   // row block: one thread per column outside the pivot block
-      for (int c = l; c < n_tail; c += nthr) {
-        if (c < p0 || c >= p0 + 6) {
-          double a[6], nw[6];
-          CSDO_FOR(j, 6, { a[j] = TINV(c, p0 + j); });
-          CSDO_FOR(k, 6, {
-            double v = 0.0;
-            CSDO_FOR(j, 6, { v = fma(pinv[k * 6 + j], a[j], v); });
-            nw[k] = v;
-          });
-          CSDO_FOR(k, 6, { TINV(c, p0 + k) = nw[k]; });
-        }
-      }
-    }
-    CSDO_SYNC();
-    CSDO_STHREADS(l, nthr) {   // everything outside the pivot's rows and columns
-      for (int e = l; e < n_tail * n_tail; e += nthr) {
-        const int r = e / n_tail, c = e - r * n_tail;
-        if ((r < p0 || r >= p0 + 6) && (c < p0 || c >= p0 + 6)) {
-          double v = TINV(c, r);
-          CSDO_FOR(k, 6, { v = fma(-TINV(p0 + k, r), TINV(c, p0 + k), v); });
-          TINV(c, r) = v;
-        }
-      }
-    }
-    CSDO_SYNC();
-    CSDO_STHREADS(l, nthr) {   // column block and the pivot block itself; lane 0 of the tail inverts the next pivot block
-      for (int r = l; r < n_tail; r += nthr) {
-        double nw[6];
-        if (r < p0 || r >= p0 + 6) {
-          double a[6];
-          CSDO_FOR(j, 6, { a[j] = TINV(p0 + j, r); });
-          CSDO_FOR(k, 6, {
-            double v = 0.0;
-            CSDO_FOR(j, 6, { v = fma(-a[j], pinv[j * 6 + k], v); });
-            nw[k] = v;
-          });
-        } else {
-          CSDO_FOR(k, 6, { nw[k] = pinv[(r - p0) * 6 + k]; });
-        }
-        CSDO_FOR(k, 6, { TINV(p0 + k, r) = nw[k]; });
-      }
-    }
-    CSDO_SYNC();   // (pinv is still being read above: the next pivot's inverse waits for this barrier)
-    if (p + 1 < n_piv) {
-      CSDO_TLANES(t) {
-        if (t == 0) pivot_inverse(p + 1);
-      }
-      CSDO_SYNC();
-    }
-  }
-#endif
 #if CSDO_TAIL_BIG >= 2
   if constexpr (BIGT && MODE != 3) {
     if (fold) {
@@ -1034,7 +947,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     const double spy = scp_.s, cpy = scp_.c;
     const double xr = (double)(float)(px + P.r2x * cpy), yr = (double)(float)(py + P.r2x * spy);
     BoxD br;
-    const int sr = box_at<(CSDO_BOX_CALL & 2) != 0>(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
+    const int sr = box_at(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
     CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
     CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
     SU(n_block_fields - 1, t) = ((sr >> 1) > 0) ? 1.0 : 0.0;
@@ -1046,7 +959,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     const double spy = scp_.s, cpy = scp_.c;
     const double xf = (double)(float)(px + P.f2x * cpy), yf = (double)(float)(py + P.f2x * spy);
     BoxD bf;
-    const int sf = box_at<(CSDO_BOX_CALL & 1) != 0>(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
+    const int sf = box_at(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
     CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
     CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
     SU(n_block_fields - 2, t) = ((sf >> 1) > 0) ? 1.0 : 0.0;
@@ -1126,7 +1039,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
     // coefficients.  The compiler had made the same choice of its own - nine doubles of the lane in scratch across the pass loop,
     // 21 reloads and 9 stores per pass, most of them waited for one by one -; parked by the program they are one batch of LDS reads
     // at the head of a pass and one of writes at its end.  Same operations on the same operands.
-    constexpr bool park = (CSDO_RUIZ_PARK != 0) && (MODE != 3);
+    constexpr bool park = (MODE != 3);
     CSDO_LANES(t) {
       LaneState& S = CSDO_LS(t);
       if constexpr (park) {
@@ -2456,10 +2369,10 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
               //  for before the next was issued: 27 trips to the workspace in a row at the head of every block)
               double stg[XFX > 0 ? XFX : 1], sinv_[21];
               CSDO_FOR(k, XFX, { stg[k] = FE(72 + XER + k, t); });
-              if constexpr (CSDO_SINV_LDS != 0 && MODE == 0) CSDO_FOR(k, 21, { sinv_[k] = WS(W_SINV + k, t); });
+              if constexpr (MODE == 0) CSDO_FOR(k, 21, { sinv_[k] = WS(W_SINV + k, t); });
               CSDO_STAGE();
               CSDO_FOR(k, XFX, { A2_LDS(k, t) = stg[k]; });
-              if constexpr (CSDO_SINV_LDS != 0 && MODE == 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = sinv_[k]; });
+              if constexpr (MODE == 0) CSDO_FOR(k, 21, { SH(fx, FX_ER + k, t) = sinv_[k]; });
               (void)sinv_;
             }
           }
@@ -2467,12 +2380,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (t < Nt) {
             V.ts0 = csdo_keep(tstart[t]);       // (kept in registers: re-reading them costs an L2 round trip per iteration)
             V.ts1 = csdo_keep(tstart[t + 1]);
-            // ... modes 0 and 1: in the two doubles per lane that `carry` does not use during a block (exact as doubles) - as lane
-            // state the pair was spilled and came back from scratch, behind a full wait, at the head of every iteration's rhs assembly
-            if constexpr (MODE < 2 && CSDO_TS_LDS) {
-              SH(carry, 4, t) = (double)V.ts0;
-              SH(carry, 5, t) = (double)V.ts1;
-            }
+            // (in LDS - carry's two spare doubles - instead of lane state the rhs assembly loses its two scratch reloads and the step
+            //  gets SLOWER, map100 57.99 -> 58.63 ms: the reloads were hidden, the LDS reads are not; round 5)
           }
           unsigned fl = 0;
           if (t < NtE) {
@@ -2551,8 +2460,8 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           // cluster of vehicles has several planes, and one LDS - or workspace - round trip per plane was the wave's critical path)
           auto add_planes = [&](auto lds_c) __attribute__((always_inline)) {
             constexpr bool L = decltype(lds_c)::value;
-            const int pe = (MODE < 2 && CSDO_TS_LDS) ? (int)SH(carry, 5, t) : V.ts1;
-            for (int p = (MODE < 2 && CSDO_TS_LDS) ? (int)SH(carry, 4, t) : V.ts0; p < pe; p += 3) {
+            const int pe = V.ts1;
+            for (int p = V.ts0; p < pe; p += 3) {
               double v[3][3];
               CSDO_FOR(q, 3, {
                 const int pq = (p + q < pe) ? p + q : p;
@@ -2606,7 +2515,6 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             }
           }
         });
-        static_assert(!REFINE || !CSDO_TS_LDS, "the refinement keeps the plane ranges in the solver lanes' registers");
         if constexpr (REFINE) {
           // ---- refinement (csdo_qp_parm::solve_refinement).  The reduced system H x = b, H = P + sigma I + A' R A, has the condition
           // of A' R A: a backward-stable solve of it - block cyclic reduction behaves like a Cholesky factorisation here - returns
@@ -2934,7 +2842,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double spy = scp_.s, cpy = scp_.c;
         const double xr = px + P.r2x * cpy, yr = py + P.r2x * spy;
         BoxD br;
-        box_at<(CSDO_BOX_CALL & 2) != 0>(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
+        box_at(xr, yr, sh.obs, n_obs, dimx, dimy, rv, br, box_cache);
         CD(C_CLB + 2, t) = br.x_min; CD(C_CLB + 3, t) = br.y_min;
         CD(C_CUB + 2, t) = br.x_max; CD(C_CUB + 3, t) = br.y_max;
       }
@@ -2946,7 +2854,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
         const double spy = scp_.s, cpy = scp_.c;
         const double xf = px + P.f2x * cpy, yf = py + P.f2x * spy;
         BoxD bf;
-        box_at<(CSDO_BOX_CALL & 1) != 0>(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
+        box_at(xf, yf, sh.obs, n_obs, dimx, dimy, rv, bf, box_cache);
         CD(C_CLB + 0, t) = bf.x_min; CD(C_CLB + 1, t) = bf.y_min;
         CD(C_CUB + 0, t) = bf.x_max; CD(C_CUB + 1, t) = bf.y_max;
       }

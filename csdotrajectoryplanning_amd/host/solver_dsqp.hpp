@@ -7,6 +7,7 @@
 // tests/cpp/mirror_main.cc compiles this header against stand-ins shaped like the reference's structs.
 // Link with -lcsdo_hip.
 #pragma once
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -113,6 +114,8 @@ class SolverDSQP {
     R.sqp_iters = num_iterations.data();
     R.admm_iters = admm.data();
     R.last_status = last.data();
+    std::vector<double> agent_s((size_t)Na, 0.0);
+    R.agent_seconds = agent_s.data();
     csdo_handle h = nullptr;
     const std::vector<int32_t> devs(devices.begin(), devices.end());
     int rc = devs.empty() ? csdo_dsqp_create(&h, device) : csdo_dsqp_create_multi(&h, devs.data(), (int32_t)devs.size());
@@ -131,6 +134,19 @@ class SolverDSQP {
         corridors[a][t] = Corridor{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};
       }
     admm_iterations.assign(admm.begin(), admm.end());
+    // Diagnostics.  The reference's logger_level >= 2 prints stage timers and the step size per agent and SQP iteration while it
+    // solves (sqp/dsqp_solver.cc:116-120,199-202,229-236,504-508), level >= 3 the iteration count (:258-260).  Here every agent's whole
+    // SQP runs on the device in one launch and nothing is printed from there; what the host knows afterwards is printed instead, one
+    // line per agent (per-stage cycle counts: the phase-timer build, scripts/profile_phases_sum.py).
+    if (logger_level >= 2) {
+      std::printf("csdo::SolverDSQP: %d agents, Nt = %d, kernels %.3f ms, call %.3f ms, solver status %d, initial boxes legal %d\n", Na, Nt,
+                  R.t_device * 1e3, R.t_total * 1e3, (int)R.solver_status, (int)R.initial_static_legal);
+      for (int a = 0; a < Na; ++a)
+        std::printf("  agent %d: %d planes, SQP iterations %d, ADMM iterations %d, last OSQP status %d, %.3f ms on its workgroup\n", a,
+                    (int)(off[a + 1] - off[a]), num_iterations[a], (int)admm[a], (int)last[a], agent_s[a] * 1e3);
+    }
+    if (logger_level >= 3)
+      for (int a = 0; a < Na; ++a) std::printf("iteration numbers: %d\n", num_iterations[a]);   // (:259, per agent)
     solve_status = R.solver_status;
     initial_static_legal = R.initial_static_legal != 0;
     max_individual_opt_runtime = R.t_max_individual;

@@ -109,7 +109,9 @@ typedef struct csdo_problem {
   const double* obstacles;     /* [n_obs][3]: x, y, r in input order */
   csdo_vehicle veh;
   csdo_qp_parm parm;
-  int32_t logger_level;        /* accepted for signature parity; the device path prints nothing */
+  int32_t logger_level;        /* accepted for signature parity; the library prints nothing (the C++ mirror host/solver_dsqp.hpp prints a
+                                  per-agent summary at level >= 2: counts, status, device time - the reference's stage timers of
+                                  sqp/dsqp_solver.cc:116-120,199-202,504-508 have no counterpart in a one-launch solve but the phase-timer build) */
   int32_t _pad2;
 } csdo_problem;
 

@@ -4,6 +4,7 @@
 // passes at csdo.cc:146-147 - with no conversion.  Reads a world from a flat binary file written by the Python test,
 // solves it through the mirror, writes the results back; tests/test_cpp_mirror.py compares them with the ctypes path.
 //   usage: mirror_main <in.bin> <out.bin>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -92,13 +93,16 @@ int main(int argc, char** argv) {
   try {
     // optional third argument: GPU ordinals "0,0" - the same constructor over several devices (csdo_dsqp_create_multi)
     std::vector<int> devices;
-    if (argc > 3)
+    if (argc > 3 && argv[3][0] != '-')
       for (const char* p = argv[3]; *p;) {
         devices.push_back((int)std::strtol(p, const_cast<char**>(&p), 10));
         if (*p == ',') ++p;
       }
-    csdo::SolverDSQP solver(optimize_res, x0_bar, inter_planes, dims[0], dims[1], obstacles, param, /*logger_level*/ 0,
-                            /*device*/ 0, /*vehicle*/ nullptr, devices);
+    // optional fourth argument "refine": csdo_qp_parm::solve_refinement through the constructor's last parameter
+    const bool refine = argc > 4 && std::string(argv[4]) == "refine";
+    const int logger_level = (argc > 5 && std::string(argv[5]) == "log") ? 3 : 0;   // fifth argument "log": the per-agent diagnostics
+    csdo::SolverDSQP solver(optimize_res, x0_bar, inter_planes, dims[0], dims[1], obstacles, param, logger_level,
+                            /*device*/ 0, /*vehicle*/ nullptr, devices, refine);
     FILE* o = std::fopen(argv[2], "wb");
     if (!o) return 5;
     const int32_t st[2] = {solver.getSolverStatus(), solver.get_initial_static_legal() ? 1 : 0};

@@ -24,8 +24,8 @@ def test_cpp_mirror_compiles_against_reference_shaped_types():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", [None, "0,0"])
-def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path, devices):
+@pytest.mark.parametrize("devices,refine", [(None, False), ("0,0", False), (None, True)])
+def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path, devices, refine):
     _build()
     veh, parm = veh_parm
     w, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
@@ -43,14 +43,20 @@ def test_cpp_mirror_equals_ctypes_path(gpu_handle, veh_parm, tmp_path, devices):
             f.write(np.ascontiguousarray(p["c"], dtype=np.float64).tobytes())
         f.write(np.ascontiguousarray(w.obstacles).tobytes())
     # devices "0,0": the same constructor with a device list - two child handles on the one GPU, agents split between them
-    r = subprocess.run([BIN, fin, fout] + ([devices] if devices else []), capture_output=True, text=True, timeout=300)
+    # fourth argument "refine": csdo_qp_parm::solve_refinement = 1 through the constructor's last parameter
+    r = subprocess.run([BIN, fin, fout] + ([devices or "-"] if (devices or refine) else []) + (["refine", "log"] if refine else []),
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
+    if refine:   # (fifth argument "log": logger_level 3 - one line per agent, and the reference's "iteration numbers" lines)
+        assert r.stdout.count("  agent ") == w.Na and r.stdout.count("iteration numbers: ") == w.Na and "ADMM iterations" in r.stdout
+    else:
+        assert r.stdout == ""
     raw = open(fout, "rb").read()
     status, legal = struct.unpack_from("<2i", raw, 0)
     tmax, = struct.unpack_from("<d", raw, 8)
     its = np.frombuffer(raw, np.int32, 2 * w.Na, 16).reshape(w.Na, 2)
     body = np.frombuffer(raw, np.float64, w.Na * w.Nt * 14, 16 + 8 * w.Na).reshape(w.Na, w.Nt, 14)
-    ref = gpu_handle.solve(w)
+    ref = gpu_handle.solve(w.with_parm(solve_refinement=1) if refine else w)
     assert status == ref.solver_status and legal == ref.initial_static_legal and tmax > 0
     assert np.array_equal(its[:, 0], ref.sqp_iters) and np.array_equal(its[:, 1], ref.admm_iters)
     assert np.array_equal(body[..., :6], ref.solutions) and np.array_equal(body[..., 6:], ref.corridors)

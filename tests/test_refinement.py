@@ -82,3 +82,19 @@ def test_committed_totals_against_the_arbiter(workload):
     assert n["product"] <= 1.5 * n["oracle"] + 2, n
     assert qd["product"]["median"] <= 4.0 * qd["oracle"]["median"], qd
     assert parity.TOL == 1e-4
+
+
+@pytest.mark.parametrize("L,Na", [(1, 1), (2, 2), (3, 1), (5, 3), (21, 2), (64, 2)])
+def test_refined_solve_on_edge_horizons(emu, oracle, veh_parm, L, Na):
+    """Nt = 4 (no reduction level at all), 7, 10, 16, 64 (a wave boundary), 193 (the eight-node tail), one to three vehicles, planes
+    between them: the refined program stops where the oracle stops and stays within 1e-6 of it, pair-split and one-lane form."""
+    from tests import helpers
+    veh, parm = veh_parm
+    w = helpers.straight_line_world(veh, parm, Na=Na, L=L, dim=300.0, spacing=3.5)
+    for k in (1, 3):
+        ref = oracle.solve(w.with_parm(max_iter=k), 2)
+        for mode in (0, 3):
+            got = emu.solve(w.with_parm(max_iter=k, solve_refinement=1), mode)
+            assert np.isfinite(got.solutions).all() and np.isfinite(got.corridors).all()
+            assert np.array_equal(got.admm_iters, ref.admm_iters) and np.array_equal(got.last_status, ref.last_status), (k, mode)
+            assert np.abs(got.solutions - ref.solutions).max() <= 1e-6, (k, mode)

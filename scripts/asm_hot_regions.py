@@ -17,7 +17,7 @@ block, mode = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("512", "0")
 out = os.path.join(tempfile.gettempdir(), "csdo_variant_%s_%s%s.s" % (block, mode, os.environ.get("CSDO_ASM_TAG", "")))
 extra = ["-DCSDO_ASM_MARKS"] if os.environ.get("CSDO_ASM_MARKS") else []
 cmd = ["/opt/rocm/bin/hipcc", *os.environ.get("CSDO_XFLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-       "-DCSDO_V_BLOCK=" + block, "-DCSDO_V_MODE=" + mode, "-DCSDO_V_SPLIT=1", "-S", "--cuda-device-only", *extra,
+       "-DCSDO_V_BLOCK=" + block, "-DCSDO_V_MODE=" + mode, "-DCSDO_V_SPLIT=" + os.environ.get("CSDO_V_SPLIT", "1"), "-S", "--cuda-device-only", *extra,
        "-Rpass-analysis=kernel-resource-usage", "-I" + csrc, os.path.join(csrc, "dsqp_variant.hip"), "-o", out]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 for line in err.splitlines():

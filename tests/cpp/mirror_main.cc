@@ -48,7 +48,7 @@ using namespace libMultiRobotPlanning;
 static bool rd(FILE* f, void* p, size_t n) { return std::fread(p, 1, n, f) == n; }
 
 int main(int argc, char** argv) {
-  if (argc != 3 && argc != 4) return 2;
+  if (argc < 3 || argc > 6) return 2;   // in out [devices|-] [refine] [log]
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 3;
   int32_t hdr[4];   // Na, Nt, n_obs, n_planes

@@ -18,9 +18,12 @@ using namespace csdo;
 // n_threads > 1: agents are solved concurrently (each has its own workspace slice and its own "LDS"), results unchanged
 extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_worlds, csdo_result* results, int mode,
                                        int n_threads) {
-  if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 10) return CSDO_EINVAL;   // 10: mode 0 with the rows' state in "LDS"
+  // 10: mode 0 with the rows' state in "LDS"; 20: mode 0 compiled with the tail's size as a CONSTANT (BIGT = false: what the 256-, 768-
+  // and 1024-thread kernels are; agents whose class rule asks for a larger tail are refused)
+  if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 10 && mode != 20) return CSDO_EINVAL;
   const bool rows_lds = mode == 10;
-  if (rows_lds) mode = 0;
+  const bool const_tail = mode == 20;
+  if (rows_lds || const_tail) mode = 0;
   HostBatch hb;
   const int rc = pack_worlds(worlds, n_worlds, hb);
   if (rc != CSDO_OK) return rc;
@@ -30,6 +33,7 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     int m_ = 0, r_ = 0, tail_ = TAIL_NODES;
     dsqp_agent_class(ad.Nt, hb.worlds[ad.world].n_obs, ad.n_planes, &m_, &r_, &tail_);
     ad.tail_nodes = tail_;
+    if (const_tail && tail_ != TAIL_NODES) return CSDO_EINVAL;
   }
   const int Na = (int)hb.agents.size();
   std::vector<double> rows_ws((size_t)std::max<int64_t>(hb.rows_total, 1) * ROWS_WS_STRIDE, 0.0);
@@ -117,7 +121,8 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
       else if (mode == 2) agent_program<ROLE_BOTH, 2, true, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
       else agent_program<ROLE_BOTH, 3, true, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     } else
-    if (mode == 0) agent_program<ROLE_BOTH, 0, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    if (const_tail) agent_program<ROLE_BOTH, 0, false>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    else if (mode == 0) agent_program<ROLE_BOTH, 0, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 1) agent_program<ROLE_BOTH, 1, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 2) agent_program<ROLE_BOTH, 2, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else agent_program<ROLE_BOTH, 3, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);

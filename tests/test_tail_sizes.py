@@ -70,3 +70,22 @@ def test_eight_node_tail_against_the_oracle(emu, oracle, workload, index):
         if k == 1:   # the one-lane form of the solve (mode 3) absorbs the partials of a node at a multiple of 64 in another order
             other = emu.solve_batch([wk], 3, 8)[0]
             assert np.array_equal(other.admm_iters, got.admm_iters) and np.abs(other.solutions - got.solutions).max() < 1e-6
+
+
+def test_run_time_tail_size_equals_the_compile_time_one_for_six_nodes(emu, veh_parm):
+    """The 512-thread kernels read the tail's size per agent (BIGT), the other classes are compiled with six nodes as a constant, and
+    the lane-serial build runs EVERY agent through the run-time form: for six-node agents the two must be the same program
+    (only the GPU runs had checked that).  Lane-serial build in both forms, a map50 world (256-thread class, 97 timesteps)
+    and a map100 world restricted to its six-node agents: the same bits."""
+    from csdotrajectoryplanning_amd import workloads
+    from tests import helpers
+    veh, parm = veh_parm
+    short, _ = helpers.load_golden("map50_agents15to17.npz", veh, parm)
+    w100 = workloads.build_job(workloads.workload_jobs("map100", 1)[0])[0]
+    six = [a for a, k in enumerate(np.diff(np.asarray(w100.plane_off))) if emu.agent_class(w100.Nt, len(w100.obstacles), int(k))[3] == 6]
+    assert len(six) >= 10
+    picks = [w100.subset(a, a + 1) for a in six[:12]]
+    for w in [short] + picks:
+        a, b = emu.solve_batch([w], 0, 4)[0], emu.solve_batch([w], 20, 4)[0]
+        assert np.array_equal(a.solutions, b.solutions) and np.array_equal(a.corridors, b.corridors)
+        assert np.array_equal(a.admm_iters, b.admm_iters) and np.array_equal(a.last_status, b.last_status)

@@ -200,11 +200,22 @@ bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* ve
   bool legal = true;
   const double reach = 2 * std::sqrt(2) * parm->r_trust;
   const float length = v.LF + v.LB, width = v.W;
+  // A pair whose rectangle centres are further apart than the reach plus what the four disc centres can lie off the rectangle centres
+  // (c2r to the front disc, c2r to the rear one; 1e-3 for the float roundings of the centres) cannot have a disc pair within reach: one
+  // distance instead of four for the nine pairs in ten that are nowhere near each other (same pair list; round 6: the pair search is
+  // the larger half of the 1.8 ms a single world's host bridge takes, of the 11 ms of a 50-agent instance's DO phase).
+  const double c2r = (double)((v.LF + v.LB) / 2 - v.LB);
+  const double off = std::max(std::fabs((double)v.f2x - c2r), std::fabs((double)v.r2x - c2r));
+  const double far2 = (reach + 2.0 * off + 1e-3) * (reach + 2.0 * off + 1e-3);
   for (size_t t = 0; t < Nt; ++t)
     for (int i = 0; i < Na - 1; ++i) {
       const size_t ki = (size_t)i * Nt + t;
       for (int j = i + 1; j < Na; ++j) {
         const size_t kj = (size_t)j * Nt + t;
+        {
+          const double ddx = (double)xc[ki] - (double)xc[kj], ddy = (double)yc[ki] - (double)yc[kj];
+          if (ddx * ddx + ddy * ddy > far2) continue;
+        }
         double d2 = sq(xf[ki], xf[kj]) + sq(yf[ki], yf[kj]);
         d2 = std::min(d2, sq(xf[ki], xr[kj]) + sq(yf[ki], yr[kj]));
         d2 = std::min(d2, sq(xr[ki], xf[kj]) + sq(yr[ki], yf[kj]));

@@ -70,3 +70,16 @@ def test_refined_map100_worlds_match_the_lane_serial_build_and_cost_about_twice(
     assert 1.2 < t_ref / t_plain < 3.0, (t_plain, t_ref)
     print("refinement: %.2f ms against %.2f ms for %d agents (x %.2f)" % (t_ref * 1e3, t_plain * 1e3, sum(w.Na for w in worlds), t_ref / t_plain))
     assert sum(int(s.admm_iters.sum()) for s in plain) > 0
+
+
+@pytest.mark.parametrize("workload", ["map100", "map50", "room50", "agents100", "synth1024"])
+def test_refined_full_chain_is_bit_identical_to_the_lane_serial_build(gpu_handle, emu, workload):
+    """Every agent of the five workloads with the refinement on: the HIP kernels return the lane-serial build's bits - which is what
+    lets scripts/chain_parity.py put `product_refined` against the arbiter on the CPU (tests/golden/chain_outliers_*.json `arbiter`)."""
+    from csdotrajectoryplanning_amd import workloads
+    worlds = [w.with_parm(solve_refinement=1) for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(workload, None), 8)]
+    got = gpu_handle.solve_batch(worlds)
+    ref = emu.solve_batch(worlds, 0, 16)
+    bad = [k for k, (g, r) in enumerate(zip(got, ref)) if not _same(g, r)]
+    assert not bad, bad
+    assert sum(w.Na for w in worlds) == {"map100": 3000, "map50": 1500, "room50": 600, "agents100": 1200, "synth1024": 1024}[workload]

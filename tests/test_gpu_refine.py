@@ -76,8 +76,8 @@ def test_refined_map100_worlds_match_the_lane_serial_build_and_cost_about_twice(
 def test_refined_full_chain_is_bit_identical_to_the_lane_serial_build(gpu_handle, emu, workload):
     """Every agent of the five workloads with the refinement on: the HIP kernels return the lane-serial build's bits - which is what
     lets scripts/chain_parity.py put `product_refined` against the arbiter on the CPU (tests/golden/chain_outliers_*.json `arbiter`)."""
-    from csdotrajectoryplanning_amd import workloads
-    worlds = [w.with_parm(solve_refinement=1) for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(workload, None), 8)]
+    from tests.test_gpu_sets import _set          # (the session's cache of the built sets)
+    worlds = [w.with_parm(solve_refinement=1) for w in _set(workload)]
     got = gpu_handle.solve_batch(worlds)
     ref = emu.solve_batch(worlds, 0, 16)
     bad = [k for k, (g, r) in enumerate(zip(got, ref)) if not _same(g, r)]

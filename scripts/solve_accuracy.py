@@ -162,7 +162,6 @@ def main():
             b = rhs_x + A.T @ (rv * rhs_z)
             H = (P + sigma * sp.identity(n) + A.T @ sp.diags(rv) @ A).toarray()
             Hl = H_longdouble(P, A, rv, sigma)
-            bl = rhs_x.astype(LD) + (A.T.tocsr().astype(float) @ np.zeros(m)).astype(LD)     # (placeholder, replaced below)
             Ar = A.tocsr()
             t_ = (rv.astype(LD) * rhs_z.astype(LD))
             bl = rhs_x.astype(LD).copy()

@@ -215,9 +215,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive DO-phase measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: run the sharded path with a one-rank nccl group (RCCL init, all-gather on the device buffer)")
-    ap.add_argument("--solve-refinement", action="store_true",
-                    help="csdo_qp_parm::solve_refinement = 1: every linear solve refined on the KKT residual (the accurate mode; about "
-                         "twice the kernel time) - what the flag costs, not the headline configuration")
+    ap.add_argument("--solve-refinement", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
+                    help="csdo_qp_parm::solve_refinement: 1 = every linear solve refined on the KKT residual (a second solve per iteration, "
+                         "about 1.8 x the kernel time), 2 = lagged (the residual joins the next rhs: one solve per iteration, 1.3 - 1.45 x) - "
+                         "what the accurate modes cost, not the headline configuration")
     ap.add_argument("--dry", action="store_true",
                     help="CPU check of the multi-rank plumbing: gloo, no GPU, the lane-serial host build as the solver; not a measurement")
     args = ap.parse_args()
@@ -312,7 +313,7 @@ def main():
         worlds_, infos_ = [], []
         for (w, lo, hi), (world, info) in zip(plan_, built):
             if args.solve_refinement:
-                world = world.with_parm(solve_refinement=1)
+                world = world.with_parm(solve_refinement=int(args.solve_refinement))
             worlds_.append(world if (lo == 0 and hi == world.Na) else world.subset(lo, hi))
             infos_.append(info)
         return jobs_, sizes_, plan_, my_jobs_, worlds_, infos_, balance
@@ -714,7 +715,7 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "solve_refinement": bool(args.solve_refinement),
+            "solve_refinement": int(args.solve_refinement),
             "kernel_source_hash": lib_hash,
             "kernel_source_hash_of_tree": _csdo_lib.source_hash_of_tree(),
             "strong_scaling_floor_ms": floor_ms,

@@ -86,7 +86,7 @@ inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   s.osqp_max_iter = p.osqp_max_iter;
   s.fixed_corridor = p.fixed_corridor;
   s.adaptive_rho_interval = p.adaptive_rho_interval > 0 ? p.adaptive_rho_interval : 25;
-  s.solve_refinement = p.solve_refinement != 0 ? 1 : 0;
+  s.solve_refinement = (p.solve_refinement == 1 || p.solve_refinement == 2) ? p.solve_refinement : 0;   // 1 full, 2 lagged
   // osqp_set_default_settings (OSQP 0.6.3), as used at sqp/dsqp_solver.cc:480-487
   s.rho0 = 0.1;
   s.sigma = 1e-6;

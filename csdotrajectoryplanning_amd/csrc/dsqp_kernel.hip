@@ -11,7 +11,7 @@
 
 namespace csdo {
 
-template <int BLOCK, int MODE, bool SPLIT, bool REFINE>
+template <int BLOCK, int MODE, bool SPLIT, int REFINE>
 hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream);   // dsqp_variant.hip
 
 __global__ void box_kernel(const double* __restrict__ pts, int n, const double* __restrict__ obs_aos, int n_obs,
@@ -58,26 +58,22 @@ int dsqp_workgroups_per_cu(int block, size_t lds_bytes) { return (block == 256 &
 hipError_t launch_dsqp(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream) {
   if (g.count <= 0 || workgroups <= 0) return hipSuccess;
   if (g.lds_bytes > LDS_CAP) return hipErrorInvalidValue;
-  if (B.prm.solve_refinement) {   // csdo_qp_parm::solve_refinement: the instantiations with the refinement step compiled in
-    switch (g.block * 10 + g.mode) {
-      case 2560: return launch_variant<256, 0, true, true>(B, g, workgroups, stream);
-      case 5120: return launch_variant<512, 0, true, true>(B, g, workgroups, stream);
-      case 5121: return launch_variant<512, 1, true, true>(B, g, workgroups, stream);
-      case 7682: return launch_variant<768, 2, true, true>(B, g, workgroups, stream);
-      case 7683: return launch_variant<768, 3, true, true>(B, g, workgroups, stream);
-      case 10243: return launch_variant<1024, 3, true, true>(B, g, workgroups, stream);
-    }
-    return hipErrorInvalidValue;
-  }
-  switch (g.block * 10 + g.mode) {
-    case 2560: return launch_variant<256, 0, true, false>(B, g, workgroups, stream);
-    case 5120: return launch_variant<512, 0, true, false>(B, g, workgroups, stream);
-    case 5121: return launch_variant<512, 1, true, false>(B, g, workgroups, stream);
-    case 7682: return launch_variant<768, 2, true, false>(B, g, workgroups, stream);
-    case 7683: return launch_variant<768, 3, true, false>(B, g, workgroups, stream);
-    case 10243: return launch_variant<1024, 3, true, false>(B, g, workgroups, stream);
-  }
-  return hipErrorInvalidValue;
+  const int key = g.block * 10 + g.mode;
+#define CSDO_LAUNCH_TABLE(R)                                                                   \
+  switch (key) {                                                                               \
+    case 2560: return launch_variant<256, 0, true, R>(B, g, workgroups, stream);               \
+    case 5120: return launch_variant<512, 0, true, R>(B, g, workgroups, stream);               \
+    case 5121: return launch_variant<512, 1, true, R>(B, g, workgroups, stream);               \
+    case 7682: return launch_variant<768, 2, true, R>(B, g, workgroups, stream);               \
+    case 7683: return launch_variant<768, 3, true, R>(B, g, workgroups, stream);               \
+    case 10243: return launch_variant<1024, 3, true, R>(B, g, workgroups, stream);             \
+  }                                                                                            \
+  return hipErrorInvalidValue
+  // csdo_qp_parm::solve_refinement picks the instantiations with that refinement compiled in (the default ones contain none of it)
+  if (B.prm.solve_refinement == 1) { CSDO_LAUNCH_TABLE(1); }
+  if (B.prm.solve_refinement == 2) { CSDO_LAUNCH_TABLE(2); }
+  CSDO_LAUNCH_TABLE(0);
+#undef CSDO_LAUNCH_TABLE
 }
 
 hipError_t launch_boxes(const double* pts, int n, const double* obs, int n_obs, double dimx, double dimy, double rv,

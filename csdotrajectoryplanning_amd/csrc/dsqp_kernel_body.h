@@ -114,7 +114,7 @@ __device__ __forceinline__ Shm carve_lds(const DeviceBatch& B, const int agent, 
 #if !defined(CSDO_PRIO_SOLVER)
 #define CSDO_PRIO_SOLVER 2
 #endif
-template <int BLOCK, int MODE, bool SPLIT, bool REFINE = false>
+template <int BLOCK, int MODE, bool SPLIT, int REFINE = 0>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kernel(const DeviceBatch B, const int first, const int count,
                                                              int* __restrict__ queue, const int lds_doubles) {
   extern __shared__ __align__(16) double lds[];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void dsqp_agent_kern
   }
 }
 
-template <int BLOCK, int MODE, bool SPLIT, bool REFINE>
+template <int BLOCK, int MODE, bool SPLIT, int REFINE>
 hipError_t launch_variant(const DeviceBatch& B, const LaunchGroup& g, int workgroups, hipStream_t stream) {
   auto kernel = dsqp_agent_kernel<BLOCK, MODE, SPLIT, REFINE>;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);

@@ -408,7 +408,7 @@ struct SolvRegs {           // solver lane of timestep t during an ADMM block
   int ts0, ts1;             // plane range of this timestep (CSR offsets), for the rhs assembly
   double er[ER_REG];
   double v[6], o[6];        // pair-split: operand and product of the level at hand (short-lived; lane state only for the lane-serial build)
-  double b0[6], x0[6];      // REFINE kernels only: the iteration's rhs and the first solve's x~ (dead code everywhere else)
+  double b0[6], x0[6], rl[6];   // REFINE kernels only: the iteration's rhs, the first solve's x~ (1), the lagged residual (2); dead code elsewhere
   unsigned fl;              // pair-split: what the lane does at which level (XF_* below)
 };
 typedef RowRegs LaneState;  // the row lane is the "home" of a timestep

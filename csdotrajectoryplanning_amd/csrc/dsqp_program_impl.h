@@ -821,7 +821,9 @@ CSDO_FN void bcr_factor(const Shm& sh_in, const double* rows_in, const int64_t r
 // =========================================================================================================
 // REFINE (csdo_qp_parm::solve_refinement; separate kernel instantiations, compiled out of the default ones): every ADMM iteration's
 // linear solve is followed by ONE step of iterative refinement on the residual of the KKT system - see "refinement" in the iteration.
-template <int ROLE, int MODE, bool BIGT, bool REFINE = false, class RowStore, class SolvStore>
+// REFINE: 0 off, 1 a second solve on the residual in every iteration, 2 LAGGED - the residual is formed but not solved for: it joins
+// the next iteration's rhs (one solve per iteration).
+template <int ROLE, int MODE, bool BIGT, int REFINE = 0, class RowStore, class SolvStore>
 CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh, RowStore&& lanes_r,
                            SolvStore&& lanes_s, ProgramOut& out) {
   AgentDesc ad = B.agents[agent];
@@ -2414,6 +2416,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             }
           }
           V.fl = fl;
+          if constexpr (REFINE == 2) CSDO_FOR(j, 6, { V.rl[j] = 0.0; });
         }
       }
       if (rows_lds) {   // the inter-vehicle rows' duals, slacks and timesteps live in LDS for the whole QP (nothing else uses
@@ -2479,7 +2482,11 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
           if (rows_lds) add_planes(std::true_type{});
           else add_planes(std::false_type{});
           CSDO_FOR(j, 6, { V.b[j] = r6[j]; });
-          if constexpr (REFINE) CSDO_FOR(j, 6, { V.b0[j] = r6[j]; });
+          if constexpr (REFINE == 2) {   // lagged: what the previous iteration's solve missed rides on this rhs (zero at a block's start)
+            CSDO_FOR(j, 6, { r6[j] += V.rl[j]; });
+            CSDO_FOR(j, 6, { V.b[j] = r6[j]; });
+          }
+          if constexpr (REFINE != 0) CSDO_FOR(j, 6, { V.b0[j] = r6[j]; });
         }
         // (modes 2, 3: the row lanes stream their rows' coefficients and bounds from the workspace, see the update; on the device the
         //  first two groups of rows are fetched while the row waves wait for the backward sweep)
@@ -2515,7 +2522,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             }
           }
         });
-        if constexpr (REFINE) {
+        if constexpr (REFINE != 0) {
           // ---- refinement (csdo_qp_parm::solve_refinement).  The reduced system H x = b, H = P + sigma I + A' R A, has the condition
           // of A' R A: a backward-stable solve of it - block cyclic reduction behaves like a Cholesky factorisation here - returns
           // x~ with |error| ~ cond(H) eps |x|, some fifty times the error of OSQP's LDL' of the quasi-definite KKT matrix
@@ -2568,7 +2575,7 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
             double h6[6], x3[3];
             CSDO_FOR(j, 6, { h6[j] = SH(rhs, j, t); });
             CSDO_FOR(k, 3, { x3[k] = SH(vec, k, t); });
-            CSDO_FOR(k, 6, { V.x0[k] = SH(vec, k, t); });
+            if constexpr (REFINE == 1) CSDO_FOR(k, 6, { V.x0[k] = SH(vec, k, t); });
             if (t > 0) {
               CSDO_FOR(k, 4, { h6[k] += SH(carry, k, t - 1); });
               h6[4] = fma(WS(W_P + 2, t - 1), SH(vec, 4, t - 1), h6[4]);
@@ -2582,17 +2589,24 @@ CSDO_FN void agent_program(const DeviceBatch& B, const int agent, const Shm& sh,
                 h6[2] = fma(cy, g, h6[2]);
               });
             }
-            CSDO_FOR(j, 6, { V.b[j] = V.b0[j] - h6[j]; });
+            if constexpr (REFINE == 1) CSDO_FOR(j, 6, { V.b[j] = V.b0[j] - h6[j]; });
+            // LAGGED (solve_refinement = 2): no second solve - the residual joins the NEXT iteration's rhs, so that x~_{k+1} carries the
+            // correction x~_k missed.  Between projections the ADMM state is linear in the x~'s: what one iteration lacks the next one
+            // supplies, and the missing corrections telescope to the last one instead of adding up.  Measured against the arbiter
+            // (scripts/chain_parity.py `product_lagged`): the distance of a double-precision OSQP, at 1.3 - 1.4 x the time instead of 1.8 x.
+            else CSDO_FOR(j, 6, { V.rl[j] = V.b0[j] - h6[j]; });
           }
           CSDO_SYNC();
-          solve([]() __attribute__((always_inline)) {});
-          CSDO_SLANES(t) {
-            SolvRegs& V = CSDO_SS(t);
-            double dx[6];
-            CSDO_FOR(k, 6, { dx[k] = SH(vec, k, t); });
-            CSDO_FOR(k, 6, { SH(vec, k, t) = V.x0[k] + dx[k]; });
+          if constexpr (REFINE == 1) {
+            solve([]() __attribute__((always_inline)) {});
+            CSDO_SLANES(t) {
+              SolvRegs& V = CSDO_SS(t);
+              double dx[6];
+              CSDO_FOR(k, 6, { dx[k] = SH(vec, k, t); });
+              CSDO_FOR(k, 6, { SH(vec, k, t) = V.x0[k] + dx[k]; });
+            }
+            CSDO_SYNC();
           }
-          CSDO_SYNC();
         }
         CSDO_PHASE(9);
         // ---- x, z, y updates (update_x / update_z / update_y); delta_y is only consumed by the termination test

@@ -78,14 +78,17 @@ typedef struct csdo_qp_parm {
   /* OSQP's default adaptive_rho_interval = 0 chooses the rho-update period from wall-clock timing; this backend
    * pins it (0 here means the documented default, 25). */
   int32_t adaptive_rho_interval;
-  /* Round 6, no reference counterpart: 1 = every ADMM iteration's linear solve is followed by one step of iterative refinement on the
-   * residual of OSQP's KKT system (formed through the constraint rows, not through the reduced matrix).  The backend solves the
-   * REDUCED system (P + sigma I + A' R A) x = b by block cyclic reduction, whose error is cond(H) eps |x| - about fifty times that
-   * of OSQP's LDL' of the quasi-definite KKT matrix; over an SQP chain that leaves 1.3 - 1.5 times as many agents beyond 1e-4 of
-   * the exact-arithmetic iterate path as a double-precision OSQP is (scripts/chain_parity.py against the binary128
-   * arbiter).  With the refinement the solve is as accurate as OSQP's and the count drops to OSQP's own; it costs a second solve and a
-   * pass over the rows per iteration (about twice the kernel time; separate kernel instantiations, the default ones are unchanged).
-   * 0 (default): off. */
+  /* Round 6, no reference counterpart: refinement of every ADMM iteration's linear solve on the residual of OSQP's KKT system (formed
+   * through the constraint rows, not through the reduced matrix).  The backend solves the REDUCED system (P + sigma I + A' R A) x = b by
+   * block cyclic reduction, whose error is cond(H) eps |x| - about fifty times that of OSQP's LDL' of the quasi-definite KKT matrix;
+   * over an SQP chain that leaves 1.3 - 1.5 times as many agents beyond 1e-4 of the exact-arithmetic iterate path as a
+   * double-precision OSQP leaves (scripts/chain_parity.py against the binary128 arbiter).
+   *   1: a second solve on that residual in every iteration.  The product then is CLOSER to the exact path than a double-precision
+   *      OSQP (map100: 13 agents beyond 1e-4 against OSQP's 20 and the default's 30), at about 1.8 x the kernel time.
+   *   2: LAGGED - the residual is formed but not solved for; it joins the next iteration's right-hand side, so that every x~ carries
+   *      the correction its predecessor missed (one solve and one pass over the rows per iteration): the distance of a
+   *      double-precision OSQP (map100: 19), at 1.3 - 1.45 x the time.
+   * Separate kernel instantiations: the default ones are unchanged.  0 (default) or any other value: off. */
   int32_t solve_refinement;
   int32_t _reserved;
 } csdo_qp_parm;

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CACHE = os.environ.get("CSDO_ARBITER_CACHE", "/tmp/csdo_arbiter_cache")   # outside the tree: gpurun ships the whole tree to the GPU box
-ALL = ("product", "product_refined", "oracle", "oracle_fma", "oracle_xm", "oracle_ld", "oracle_q", "oracle_qxm")
+ALL = ("product", "product_refined", "product_lagged", "oracle", "oracle_fma", "oracle_xm", "oracle_ld", "oracle_q", "oracle_qxm")
 
 
 def run(name, worlds, threads):
@@ -20,6 +20,8 @@ def run(name, worlds, threads):
         return emu_lib.solve_batch(worlds, 0, threads)
     if name == "product_refined":                         # csdo_qp_parm::solve_refinement = 1
         return emu_lib.solve_batch([with_refinement(w) for w in worlds], 0, threads)
+    if name == "product_lagged":                          # csdo_qp_parm::solve_refinement = 2
+        return emu_lib.solve_batch([with_refinement(w, 2) for w in worlds], 0, threads)
     if name == "oracle":
         return oracle_lib.solve_batch(worlds, threads)
     return oracle_lib.solve_batch_variant(worlds, name.split("_", 1)[1], threads)

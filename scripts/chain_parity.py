@@ -15,6 +15,7 @@ of the reference algorithm on the same double-precision QP data:
   oracle_fma, oracle_xm vs oracle_q     the same for the oracle's other builds
   product              vs oracle_qxm    the product against the exact path with ITS trigonometry: formulation + rounding of the solve alone
   product_refined      vs oracle_q      the product with csdo_qp_parm::solve_refinement = 1 (one refinement step on the KKT residual per solve)
+  product_lagged       vs oracle_q      ... = 2 (the residual joins the next iteration's rhs: one solve per iteration)
 The arbiter takes minutes per workload: whole-workload results are cached under oracle/_cache (scripts/arbiter_run.py).
 Every outlier (|product - oracle| > 1e-4 or different counts) is then run alone with QpParm.max_iter = 1..10 on all of them,
 and the cut at which it parts from the oracle is classified: a termination check that flips (ADMM counts differ at that cut),
@@ -86,6 +87,7 @@ def main():
     worlds = [w for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(args.workload, args.instances), args.threads)]
     solvers = {"product": lambda ws: emu_lib.solve_batch(ws, 0, args.threads),
                "product_refined": lambda ws: emu_lib.solve_batch([arbiter_run.with_refinement(w) for w in ws], 0, args.threads),
+               "product_lagged": lambda ws: emu_lib.solve_batch([arbiter_run.with_refinement(w, 2) for w in ws], 0, args.threads),
                "oracle": lambda ws: oracle_lib.solve_batch(ws, args.threads),
                "oracle_xm": lambda ws: oracle_lib.solve_batch_xm(ws, args.threads),
                "oracle_fma": lambda ws: oracle_lib.solve_batch_fma(ws, args.threads),
@@ -118,7 +120,8 @@ def main():
         assert n_bad == 0, "%d worlds differ between HIP and the lane-serial build" % n_bad
     pairs = [("product", "oracle"), ("product", "oracle_xm"), ("oracle_xm", "oracle"), ("oracle_fma", "oracle"),
              ("product", "oracle_q"), ("oracle", "oracle_q"), ("oracle_fma", "oracle_q"), ("oracle_xm", "oracle_q"),
-             ("product", "oracle_qxm"), ("oracle_xm", "oracle_qxm"), ("product_refined", "oracle_q"), ("product_refined", "oracle")]
+             ("product", "oracle_qxm"), ("oracle_xm", "oracle_qxm"), ("product_refined", "oracle_q"), ("product_refined", "oracle"),
+             ("product_lagged", "oracle_q")]
     per = {}
     for a, b in pairs:
         per[(a, b)] = per_agent(full[a], full[b])
@@ -188,11 +191,14 @@ def main():
         "what": "oracle_q = the oracle with OSQP's linear algebra in IEEE binary128 (double-precision QP data, x* rounded to double per QP)",
         "beyond_1e-4_or_other_counts": {"product": int((~spq | (dpq > 1e-4)).sum()), "oracle": int((~soq | (doq > 1e-4)).sum()),
                                         "product_refined": int((~per[("product_refined", "oracle_q")][2] | (per[("product_refined", "oracle_q")][0] > 1e-4)).sum()),
+                                        "product_lagged": int((~per[("product_lagged", "oracle_q")][2] | (per[("product_lagged", "oracle_q")][0] > 1e-4)).sum()),
                                         "oracle_fma": report["pairs"]["oracle_fma_vs_oracle_q"]["n_gt_1e-4"],
                                         "oracle_xm": report["pairs"]["oracle_xm_vs_oracle_q"]["n_gt_1e-4"]},
         "quantiles_of_d": {"product": {"median": q(dpq, .5), "p90": q(dpq, .9), "p99": q(dpq, .99), "max": float(dpq.max())},
                            "product_refined": {"median": q(per[("product_refined", "oracle_q")][0], .5), "p90": q(per[("product_refined", "oracle_q")][0], .9),
                                                "p99": q(per[("product_refined", "oracle_q")][0], .99), "max": float(per[("product_refined", "oracle_q")][0].max())},
+                           "product_lagged": {"median": q(per[("product_lagged", "oracle_q")][0], .5), "p90": q(per[("product_lagged", "oracle_q")][0], .9),
+                                              "p99": q(per[("product_lagged", "oracle_q")][0], .99), "max": float(per[("product_lagged", "oracle_q")][0].max())},
                            "oracle": {"median": q(doq, .5), "p90": q(doq, .9), "p99": q(doq, .99), "max": float(doq.max())}},
         "agents_where_the_product_is_closer_to_q_than_the_oracle_is": int((dpq < doq).sum()),
         "beyond_1e-4_of_q_both": int(((dpq > 1e-4) & (doq > 1e-4)).sum()),

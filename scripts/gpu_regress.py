@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--against-emu", action="store_true",
                     help="compare every array with the lane-serial host build of the same source (tests/emu), agent by agent")
     ap.add_argument("--threads", type=int, default=16)
-    ap.add_argument("--solve-refinement", action="store_true", help="csdo_qp_parm::solve_refinement = 1 on every world (the REFINE kernels)")
+    ap.add_argument("--solve-refinement", type=int, nargs="?", const=1, default=0, help="csdo_qp_parm::solve_refinement (1 or 2) on every world (the REFINE kernels)")
     args = ap.parse_args()
     import torch  # noqa: F401  (first: the HIP runtime of the process)
     from csdotrajectoryplanning_amd import workloads
@@ -29,7 +29,7 @@ def main():
     for name in args.workload.split(","):
         worlds = [w for w, _ in workloads.build_jobs_parallel(workloads.workload_jobs(name, args.instances), 8)]
         if args.solve_refinement:
-            worlds = [w.with_parm(solve_refinement=1) for w in worlds]
+            worlds = [w.with_parm(solve_refinement=args.solve_refinement) for w in worlds]
         h = DsqpHandle(0)
         got = h.solve_batch(worlds)
         if args.against_emu:

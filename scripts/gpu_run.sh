@@ -58,8 +58,10 @@ PY
       bash scripts/profile_round.sh $TAG $arg ;;
     refined)   # what csdo_qp_parm::solve_refinement costs: the same bench lines with the flag on
       for w in ${arg//,/ }; do
-        timeout 600 python bench.py --workload $w --solve-refinement --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_refined_$w.json 2> $O/bench_refined_$w.err; echo "bench refined $w rc=$?"
-        python -c "import json,sys; d=json.load(open(sys.argv[1])); print('  refined %s: %.2f M it/s  %.2f ms/step  single %.2f ms' % (sys.argv[2], d['value']/1e6, d['ms_per_step'], d['single_instance']['do_phase_ms']['solve_kernel']))" $O/bench_refined_$w.json $w
+        for m in 1 2; do
+          timeout 600 python bench.py --workload $w --solve-refinement $m --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_refined${m}_$w.json 2> $O/bench_refined${m}_$w.err; echo "bench solve_refinement=$m $w rc=$?"
+          python -c "import json,sys; d=json.load(open(sys.argv[1])); print('  solve_refinement %s, %s: %.2f M it/s  %.2f ms/step  single %.2f ms' % (sys.argv[3], sys.argv[2], d['value']/1e6, d['ms_per_step'], d['single_instance']['do_phase_ms']['solve_kernel']))" $O/bench_refined${m}_$w.json $w $m
+        done
       done ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log ;;

@@ -115,11 +115,16 @@ extern "C" int csdo_emu_solve_batch_mt(const csdo_problem* worlds, int32_t n_wor
     std::vector<RowRegs> lanes_r(ad.Nt);
     std::vector<SolvRegs> lanes_s(std::max<int>(ad.Nt + 2, TAIL_N_BIG));   // (+ the partner lane of a last, even node)
     ProgramOut po{};
-    if (hb.prm.solve_refinement) {   // csdo_qp_parm::solve_refinement: the program with the refinement step compiled in
-      if (mode == 0) agent_program<ROLE_BOTH, 0, true, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-      else if (mode == 1) agent_program<ROLE_BOTH, 1, true, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-      else if (mode == 2) agent_program<ROLE_BOTH, 2, true, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
-      else agent_program<ROLE_BOTH, 3, true, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    if (hb.prm.solve_refinement == 1) {   // csdo_qp_parm::solve_refinement: the program with that refinement compiled in
+      if (mode == 0) agent_program<ROLE_BOTH, 0, true, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+      else if (mode == 1) agent_program<ROLE_BOTH, 1, true, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+      else if (mode == 2) agent_program<ROLE_BOTH, 2, true, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+      else agent_program<ROLE_BOTH, 3, true, 1>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+    } else if (hb.prm.solve_refinement == 2) {
+      if (mode == 0) agent_program<ROLE_BOTH, 0, true, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+      else if (mode == 1) agent_program<ROLE_BOTH, 1, true, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+      else if (mode == 2) agent_program<ROLE_BOTH, 2, true, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
+      else agent_program<ROLE_BOTH, 3, true, 2>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     } else
     if (const_tail) agent_program<ROLE_BOTH, 0, false>(B, a, sh, lanes_r.data(), lanes_s.data(), po);
     else if (mode == 0) agent_program<ROLE_BOTH, 0, true>(B, a, sh, lanes_r.data(), lanes_s.data(), po);

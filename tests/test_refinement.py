@@ -52,13 +52,17 @@ def test_refined_solve_is_closer_to_the_exact_path_than_a_double_precision_osqp(
     wr = [w.with_parm(max_iter=n_qp, solve_refinement=1) for w in worlds]
     q, o = oracle.solve_batch_variant(ws, "q", THREADS), oracle.solve_batch(ws, THREADS)
     plain, refined = emu.solve_batch(ws, 0, THREADS), emu.solve_batch(wr, 0, THREADS)
-    assert _same_counts(plain, q) and _same_counts(refined, q) and _same_counts(o, q)
-    d_o, d_p, d_r = _d(o, q), _d(plain, q), _d(refined, q)
-    print("QPs %d: median / p90 distance to the arbiter: oracle %.1e / %.1e, product %.1e / %.1e, product refined %.1e / %.1e" % (
-        n_qp, np.median(d_o), np.quantile(d_o, .9), np.median(d_p), np.quantile(d_p, .9), np.median(d_r), np.quantile(d_r, .9)))
+    lagged = emu.solve_batch([w.with_parm(max_iter=n_qp, solve_refinement=2) for w in worlds], 0, THREADS)
+    assert _same_counts(plain, q) and _same_counts(refined, q) and _same_counts(o, q) and _same_counts(lagged, q)
+    d_o, d_p, d_r, d_l = _d(o, q), _d(plain, q), _d(refined, q), _d(lagged, q)
+    print("QPs %d: median / p90 distance to the arbiter: oracle %.1e / %.1e, product %.1e / %.1e, refined %.1e / %.1e, lagged %.1e / %.1e" % (
+        n_qp, np.median(d_o), np.quantile(d_o, .9), np.median(d_p), np.quantile(d_p, .9), np.median(d_r), np.quantile(d_r, .9),
+        np.median(d_l), np.quantile(d_l, .9)))
     assert np.median(d_r) <= np.median(d_o) and np.quantile(d_r, .9) <= np.quantile(d_o, .9)      # refined: closer than OSQP in double
     assert np.median(d_p) >= 2.0 * np.median(d_r)                                               # and that is the refinement's doing
     assert d_r.max() <= 1e-6 and d_p.max() <= 1e-5
+    # the lagged form (one solve per iteration): about the distance of a double-precision OSQP, well inside the unrefined product's
+    assert np.median(d_l) <= 1.5 * np.median(d_o) and np.median(d_l) <= 0.6 * np.median(d_p) and d_l.max() <= 1e-6
     # the other residency modes run the same refinement: the pair-split modes to the bit, the one-lane form to rounding
     for mode in (1, 2):
         other = emu.solve_batch(wr, mode, THREADS)
@@ -79,6 +83,8 @@ def test_committed_totals_against_the_arbiter(workload):
     qd = fx["arbiter"]["quantiles_of_d"]
     assert n["product_refined"] <= n["oracle"], n
     assert qd["product_refined"]["median"] <= qd["oracle"]["median"] and qd["product_refined"]["p90"] <= qd["oracle"]["p90"], qd
+    # the lagged refinement (solve_refinement = 2, one solve per iteration): no further than the oracle either - by a smaller margin
+    assert n["product_lagged"] <= n["oracle"] and qd["product_lagged"]["median"] <= qd["oracle"]["median"], (n, qd)
     assert n["product"] <= 1.5 * n["oracle"] + 2, n
     assert qd["product"]["median"] <= 4.0 * qd["oracle"]["median"], qd
     assert parity.TOL == 1e-4
@@ -94,7 +100,8 @@ def test_refined_solve_on_edge_horizons(emu, oracle, veh_parm, L, Na):
     for k in (1, 3):
         ref = oracle.solve(w.with_parm(max_iter=k), 2)
         for mode in (0, 3):
-            got = emu.solve(w.with_parm(max_iter=k, solve_refinement=1), mode)
-            assert np.isfinite(got.solutions).all() and np.isfinite(got.corridors).all()
-            assert np.array_equal(got.admm_iters, ref.admm_iters) and np.array_equal(got.last_status, ref.last_status), (k, mode)
-            assert np.abs(got.solutions - ref.solutions).max() <= 1e-6, (k, mode)
+            for refinement in (1, 2):
+                got = emu.solve(w.with_parm(max_iter=k, solve_refinement=refinement), mode)
+                assert np.isfinite(got.solutions).all() and np.isfinite(got.corridors).all()
+                assert np.array_equal(got.admm_iters, ref.admm_iters) and np.array_equal(got.last_status, ref.last_status), (k, mode, refinement)
+                assert np.abs(got.solutions - ref.solutions).max() <= 1e-6, (k, mode, refinement)

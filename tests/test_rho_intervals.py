@@ -44,6 +44,7 @@ def test_lane_serial_build_against_oracle(emu, oracle, veh_parm, interval, cap):
             ref = oracle.solve(w, 4)
             _meets_the_bar(emu.solve(w), ref, n_qp)
             _meets_the_bar(emu.solve(w.with_parm(solve_refinement=1)), ref, n_qp)     # the refined solve (round 6): the same bar, every combination
+            _meets_the_bar(emu.solve(w.with_parm(solve_refinement=2)), ref, n_qp)     # ... and its lagged form
             if n_qp == 1:
                 assert ref.admm_iters.max() <= cap and np.all(ref.admm_iters % 25 == 0)       # termination is tested every 25 iterations
 

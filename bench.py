@@ -563,8 +563,11 @@ def main():
                         "agent_qp_iterations_per_sec": iters_step / best_s["total"],
                         "in_chunks": bool(best_s["streamed"]),
                         "results_equal_the_resident_batch": bool(same),
+                        "results_written_to_host_memory_by_the_kernels": True,
                         "note": "best of 3 after a first pass; host wall clock from the coarse paths to the results in the "
                                 "caller's arrays; chunk k + 1 is bridged (host threads), packed and copied under chunk k's solve; "
+                                "every workgroup writes its agent's results into page-locked host memory when the agent is done "
+                                "(csdo_dsqp_set_host_results): nothing is copied behind the last kernel, only scattered; "
                                 "a job of several kernel classes (in_chunks false) is bridged by one device call and solved by "
                                 "one launch instead"}
         e2e = {"total_ms": (streamed["total_ms"] if streamed else tot * 1e3),

@@ -55,6 +55,7 @@ def lib():
         L.csdo_dsqp_launch_groups.argtypes = [H, C.POINTER(abi.LaunchGroup), C.c_int32]
         L.csdo_dsqp_launch_groups.restype = C.c_int32
         L.csdo_dsqp_set_min_residency_mode.argtypes = [H, C.c_int32]
+        L.csdo_dsqp_set_host_results.argtypes = [H, C.c_int32]
         L.csdo_dsqp_agent_groups.argtypes = [H, abi.c_int32_p, C.c_int32]
         L.csdo_dsqp_device_solutions.argtypes = [H, C.POINTER(C.c_int64)]
         L.csdo_dsqp_device_solutions.restype = C.c_void_p

@@ -102,7 +102,7 @@ class LaunchGroup(C.Structure):
 
 EXPORTED_SYMBOLS = (
     "csdo_dsqp_create", "csdo_dsqp_create_multi", "csdo_dsqp_multi_count", "csdo_dsqp_multi_child", "csdo_dsqp_shard_bounds", "csdo_dsqp_destroy", "csdo_dsqp_solve", "csdo_dsqp_solve_batch", "csdo_dsqp_upload",
-    "csdo_dsqp_run", "csdo_dsqp_run_async", "csdo_dsqp_wait", "csdo_dsqp_create_shared", "csdo_dsqp_set_lane", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_last_transfer_seconds", "csdo_dsqp_launch_groups", "csdo_dsqp_agent_groups", "csdo_dsqp_set_min_residency_mode",
+    "csdo_dsqp_run", "csdo_dsqp_run_async", "csdo_dsqp_wait", "csdo_dsqp_create_shared", "csdo_dsqp_set_lane", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_last_transfer_seconds", "csdo_dsqp_launch_groups", "csdo_dsqp_agent_groups", "csdo_dsqp_set_min_residency_mode", "csdo_dsqp_set_host_results",
     "csdo_dsqp_device_solutions",
     "csdo_preprocess", "csdo_preprocess_device", "csdo_preprocess_device_batch", "csdo_preprocess_batch", "csdo_dsqp_estimate_work", "csdo_dsqp_agent_class", "csdo_dsqp_last_limit", "csdo_front_end_gate_draws", "csdo_bridge_free", "csdo_validate", "csdo_validate_frames", "csdo_generate_boxes", "csdo_math_eval", "csdo_vehicle_default",
     "csdo_qp_parm_default", "csdo_backend_name", "csdo_source_hash",

@@ -6,11 +6,13 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
 #include "../../include/csdo_dsqp.h"
 #include "csdo_device_types.h"
+#include "host_pool.h"
 
 namespace csdo {
 
@@ -33,41 +35,12 @@ struct HostBatch {
 
 inline int fac_stride(int Nt) { return (Nt + 1) & ~1; }
 
-// body(i) for i in [0, n) on up to max_threads host threads (the calling thread is one of them).  Nothing escapes: a thread
-// that cannot be created (the caller's cgroup may cap them) just is not there - the started ones take its share -, a body that
-// throws (std::bad_alloc in a growing vector) is recorded, every started thread is joined on every path.  Returns CSDO_OK, or
-// CSDO_ENOMEM if a body threw.
-template <class F>
-inline int parallel_for(const int n, const int max_threads, F&& body) {
-  std::atomic<int> next{0}, failed{0};
-  auto run = [&]() {
-    for (;;) {
-      const int i = next.fetch_add(1);
-      if (i >= n) break;
-      try {
-        body(i);
-      } catch (...) {
-        failed.store(1);
-      }
-    }
-  };
-  const int n_thr = std::max(1, std::min({n, max_threads, (int)std::thread::hardware_concurrency()}));
-  struct Joiner {
-    std::vector<std::thread> thr;
-    ~Joiner() {
-      for (auto& t : thr)
-        if (t.joinable()) t.join();
-    }
-  } pool;
-  try {
-    pool.thr.reserve((size_t)n_thr);
-    for (int k = 1; k < n_thr; ++k) pool.thr.emplace_back(run);
-  } catch (...) {   // std::system_error (thread limit) / std::bad_alloc: go on with the threads there are
-  }
-  run();
-  for (auto& t : pool.thr) t.join();
-  return failed.load() ? CSDO_ENOMEM : CSDO_OK;
-}
+// The four big arrays of a packed batch (x0, planes, tstart, obstacles: 30 MB for 2000 vehicles) live in the batch's own vectors, or
+// where the caller of pack_worlds has them put: capi.hip hands out slots of its page-locked staging arena, so that nothing is zeroed,
+// page-faulted in or copied a second time per upload.  The placer is called once, with the element counts, before anything is filled.
+struct PackSizes { size_t agents, worlds, x0, planes, tstart, obstacles; };
+struct PackPlace { double* x0; PlaneDev* planes; int32_t* tstart; double* obstacles; };
+using PackPlacer = std::function<int(const PackSizes&, PackPlace&)>;
 
 inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   SolverParams s{};
@@ -100,10 +73,10 @@ inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   return s;
 }
 
-// returns CSDO_OK or an error code.  Two passes: sizes and offsets of every world (serial, cheap), then the worlds are
-// filled in parallel by a few host threads (the per-agent plane ordering and the work estimate - a cos / sin per plane -
+// returns CSDO_OK or an error code.  Two passes: sizes and offsets of every world (serial, cheap), then blocks of agents are
+// filled in parallel by the library's host threads (the per-agent plane ordering and the work estimate - a cos / sin per plane -
 // are what takes time: 41 ms single-threaded for the 3000-agent batch).
-inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) {
+inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb, const PackPlacer* placer = nullptr) {
   if (!worlds || n_worlds < 1) return CSDO_EINVAL;
   hb = HostBatch{};
   hb.prm = make_params(worlds[0].veh, worlds[0].parm);
@@ -146,30 +119,48 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
   hb.est_work.resize(cur.agent);
   hb.launch_rank.resize(cur.agent);
   hb.worlds.resize(n_worlds);
-  hb.x0.resize(cur.x0);
-  hb.planes.resize(cur.plane);
-  hb.tstart.resize(cur.tstart);
-  hb.obstacles.resize(cur.obs);
+  PackPlace at{nullptr, nullptr, nullptr, nullptr};
+  if (placer) {
+    const int prc_ = (*placer)(PackSizes{cur.agent, (size_t)n_worlds, cur.x0, cur.plane, cur.tstart, cur.obs}, at);
+    if (prc_ != CSDO_OK) return prc_;
+  } else {
+    hb.x0.resize(cur.x0);
+    hb.planes.resize(cur.plane);
+    hb.tstart.resize(cur.tstart);
+    hb.obstacles.resize(cur.obs);
+    at = PackPlace{hb.x0.data(), hb.planes.data(), hb.tstart.data(), hb.obstacles.data()};
+  }
   hb.rows_total = cur.rows;
   hb.fac_total = cur.fac;
   hb.steps_total = cur.steps;
   std::atomic<int> err{CSDO_OK}, max_planes{0};
-  auto fill = [&](const int w) {
+  // the unit of host work is a block of agents of one world (a streamed DO phase's first chunk is five worlds: per world, it would
+  // be five threads' work whatever the machine has)
+  constexpr int AGENT_BLOCK = 8;
+  std::vector<std::pair<int32_t, int32_t>> items;
+  for (int w = 0; w < n_worlds; ++w)
+    for (int a0 = 0; a0 < worlds[w].Na; a0 += AGENT_BLOCK) items.emplace_back(w, a0);
+  auto fill = [&](const int item) {
     {
+      const int w = items[(size_t)item].first, a_lo = items[(size_t)item].second;
       const csdo_problem& W = worlds[w];
+      const int a_hi = std::min(a_lo + AGENT_BLOCK, (int)W.Na);
       const Off& o = off[w];
-      WorldDesc wd{};
-      wd.dimx = W.dimx;
-      wd.dimy = W.dimy;
-      wd.obs_off = (int32_t)(o.obs / 3);
-      wd.n_obs = W.n_obs;
-      hb.worlds[w] = wd;
-      if (W.n_obs) std::memcpy(hb.obstacles.data() + o.obs, W.obstacles, sizeof(double) * 3 * (size_t)W.n_obs);
-      std::memcpy(hb.x0.data() + o.x0, W.x0_bar, sizeof(double) * (size_t)W.Na * W.Nt * 6);
-      int64_t rows = o.rows, fac = o.fac, steps = o.steps;
+      if (a_lo == 0) {
+        WorldDesc wd{};
+        wd.dimx = W.dimx;
+        wd.dimy = W.dimy;
+        wd.obs_off = (int32_t)(o.obs / 3);
+        wd.n_obs = W.n_obs;
+        hb.worlds[w] = wd;
+        if (W.n_obs) std::memcpy(at.obstacles + o.obs, W.obstacles, sizeof(double) * 3 * (size_t)W.n_obs);
+      }
+      std::memcpy(at.x0 + o.x0 + (size_t)a_lo * W.Nt * 6, W.x0_bar + (size_t)a_lo * W.Nt * 6,
+                  sizeof(double) * (size_t)(a_hi - a_lo) * W.Nt * 6);
+      const int64_t fac_per_agent = (int64_t)(FAC_E_DOUBLES + FAC_X_DOUBLES + COLD_DOUBLES) * fac_stride(W.Nt);
       std::vector<int> order, near_obs;
       std::vector<int32_t> ts((size_t)W.Nt + 1);
-      for (int a = 0; a < W.Na; ++a) {
+      for (int a = a_lo; a < a_hi; ++a) {
         AgentDesc ad{};
         ad.Nt = W.Nt;
         ad.world = w;
@@ -185,7 +176,7 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
         std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return W.planes[p].t < W.planes[q].t; });
         ad.tstart_off = (int64_t)(o.tstart + (size_t)a * (W.Nt + 1));
         std::fill(ts.begin(), ts.end(), 0);
-        PlaneDev* dst = hb.planes.data() + ad.plane_off;
+        PlaneDev* dst = at.planes + ad.plane_off;
         // Launch order.  A few per cent of the agents take 3-6x the median time (QPs that run to the iteration cap for
         // most SQP iterations) and decide the makespan of a batch unless they start early.  Measured on the two benchmark
         // sets with this repository's front-end paths (scripts/agent_times.py, 4500 agents): what marks them is a tight
@@ -248,21 +239,18 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
           n_near += near;
         }
         for (int t = 0; t < W.Nt; ++t) ts[t + 1] += ts[t];
-        std::memcpy(hb.tstart.data() + ad.tstart_off, ts.data(), sizeof(int32_t) * ts.size());
+        std::memcpy(at.tstart + ad.tstart_off, ts.data(), sizeof(int32_t) * ts.size());
         const double tight = (n_near + 0.2 * n_violated) / (double)W.Nt;
         hb.launch_rank[o.agent + a] = (float)tight;
         hb.est_work[o.agent + a] = (float)((1.0 + 10.0 * std::min(tight, 1.0)) * (2.0 * W.Nt + ad.n_planes));
-        ad.rows_off = rows;
-        rows += (int64_t)4 * ad.n_planes;
-        ad.fac_off = fac;
-        fac += (int64_t)(FAC_E_DOUBLES + FAC_X_DOUBLES + COLD_DOUBLES) * fac_stride(W.Nt);
-        ad.out_off = steps;
-        steps += W.Nt;
+        ad.rows_off = o.rows + (int64_t)4 * k0;
+        ad.fac_off = o.fac + (int64_t)a * fac_per_agent;
+        ad.out_off = o.steps + (int64_t)a * W.Nt;
         hb.agents[o.agent + a] = ad;
       }
     }
   };
-  const int prc = parallel_for(n_worlds, 16, fill);
+  const int prc = parallel_for((int)items.size(), 64, fill);
   hb.max_planes = max_planes.load();
   return err.load() != CSDO_OK ? err.load() : prc;
 }
@@ -272,14 +260,16 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb) 
 inline void unpack_results(const HostBatch& hb, const csdo_problem* worlds, int n_worlds, const double* sol,
                            const double* corr, const int32_t* sqp_iters, const int32_t* admm_iters,
                            const int32_t* last_status, const int32_t* static_legal, csdo_result* results) {
-  // worlds are independent: scattered by a few host threads (57 MB for the 3000-agent batch, first touch of the caller's pages)
-  auto scatter = [&](const int w) {
-   {
-    const int a0 = hb.world_first_agent[w], a1 = hb.world_first_agent[w + 1];
+  // blocks of agents scattered by the host threads (57 MB for the 3000-agent batch); the worlds' aggregates afterwards
+  constexpr int AGENT_BLOCK = 16;
+  std::vector<std::pair<int32_t, int32_t>> items;
+  for (int w = 0; w < n_worlds; ++w)
+    for (int a = hb.world_first_agent[w]; a < hb.world_first_agent[w + 1]; a += AGENT_BLOCK) items.emplace_back(w, a);
+  auto scatter = [&](const int item) {
+    const int w = items[(size_t)item].first, a0 = hb.world_first_agent[w];
+    const int a_lo = items[(size_t)item].second, a_hi = std::min(a_lo + AGENT_BLOCK, (int)hb.world_first_agent[w + 1]);
     csdo_result& R = results[w];
-    bool any_bad = false;
-    int worst = 2, legal = 1;
-    for (int a = a0; a < a1; ++a) {
+    for (int a = a_lo; a < a_hi; ++a) {
       const AgentDesc& ad = hb.agents[a];
       const int la = a - a0;
       std::memcpy(R.solutions + (size_t)la * ad.Nt * 6, sol + ad.out_off * 6, sizeof(double) * ad.Nt * 6);
@@ -287,6 +277,13 @@ inline void unpack_results(const HostBatch& hb, const csdo_problem* worlds, int 
       R.sqp_iters[la] = sqp_iters[a];
       R.admm_iters[la] = admm_iters[a];
       R.last_status[la] = last_status[a];
+    }
+  };
+  (void)parallel_for((int)items.size(), 64, scatter);
+  for (int w = 0; w < n_worlds; ++w) {
+    bool any_bad = false;
+    int worst = 2, legal = 1;
+    for (int a = hb.world_first_agent[w]; a < hb.world_first_agent[w + 1]; ++a) {
       const int s = last_status[a];
       if (std::abs(s) > 1) {
         any_bad = true;
@@ -294,12 +291,10 @@ inline void unpack_results(const HostBatch& hb, const csdo_problem* worlds, int 
       }
       if (!static_legal[a]) legal = 0;
     }
-    R.solver_status = any_bad ? worst : 1;
-    R.initial_static_legal = legal;
-    (void)worlds;
-   }
-  };
-  (void)parallel_for(n_worlds, 16, scatter);
+    results[w].solver_status = any_bad ? worst : 1;
+    results[w].initial_static_legal = legal;
+  }
+  (void)worlds;
 }
 
 }  // namespace csdo

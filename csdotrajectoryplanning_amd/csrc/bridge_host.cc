@@ -3,14 +3,23 @@
 #include "bridge_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
+
+#include "host_pool.h"
 
 namespace csdo {
 
 namespace {
+
+// One world's bridge is cut into pieces - agents, blocks of timesteps, blocks of pairs - for up to this many of the library's host
+// threads: a single 50-vehicle instance is 1.3 ms of bridge on one thread, a streamed DO phase's first chunk is five worlds on a
+// machine with a few dozen cores.  The pieces write disjoint outputs; the pair list is concatenated in (t, i, j) order.
+constexpr int HOST_THREADS_PER_WORLD = 16;
 
 struct Veh {
   float r, LF, LB, W, f2x, r2x, rv;
@@ -99,14 +108,15 @@ int bridge_interpolate(const double* states, const int32_t* actions, const int32
   const int n = parm->num_interpolation;
   const double dt = parm->dt;
 
-  // ---- interpolation (interpolateXYYaw :277-310) ----
+  // ---- interpolation (interpolateXYYaw :277-310), the agents side by side on the library's host threads ----
   std::vector<std::vector<double>> X(Na), Y(Na), YAW(Na);
   std::vector<std::vector<int>> ACT(Na);
-  int act_base = 0;
-  size_t Nt = 0;
-  for (int a = 0; a < Na; ++a) {
+  for (int a = 0; a < Na; ++a)
+    if (path_off[a + 1] - path_off[a] < 1) return CSDO_EINVAL;
+  std::atomic<int> bad{0};
+  int prc = parallel_for(Na, HOST_THREADS_PER_WORLD, [&](const int a) {
     const int L = path_off[a + 1] - path_off[a];
-    if (L < 1) return CSDO_EINVAL;
+    const int act_base = (path_off[a] - path_off[0]) - a;   // L - 1 actions per earlier agent
     const double* S = states + (size_t)path_off[a] * 3;
     double cur[3] = {S[0], S[1], S[2]};
     if (L == 1) {  // single-state path: the goal overwrite applies to it
@@ -125,15 +135,20 @@ int bridge_interpolate(const double* states, const int32_t* actions, const int32
         nxt[2] = goals[3 * a + 2];
       }
       const int act = actions[act_base + i];
-      if (act < 0 || act > 6) return CSDO_EINVAL;
+      if (act < 0 || act > 6) {
+        bad.store(1);
+        return;
+      }
       refine_segment(act, cur, nxt, n, v, X[a], Y[a], YAW[a], ACT[a]);
       cur[0] = X[a].back();
       cur[1] = Y[a].back();
       cur[2] = YAW[a].back();
     }
-    act_base += L - 1;
-    Nt = std::max(Nt, X[a].size());
-  }
+  });
+  if (bad.load()) return CSDO_EINVAL;
+  if (prc != CSDO_OK) return prc;
+  size_t Nt = 0;
+  for (int a = 0; a < Na; ++a) Nt = std::max(Nt, X[a].size());
   if (Nt < 2) return CSDO_EINVAL;
 
   // ---- fixed-length guess with steer / v / d_steer (calcVSteerW :315-411) ----
@@ -142,7 +157,14 @@ int bridge_interpolate(const double* states, const int32_t* actions, const int32
   out->x0_bar = (double*)std::calloc((size_t)Na * Nt * 6, sizeof(double));
   if (!out->x0_bar) return CSDO_ENOMEM;
   const double phi = (double)std::atan((v.LF - v.LB) / v.r);  // float atan (:352-353)
-  for (int a = 0; a < Na; ++a) {
+  // ---- ... and the float disc centres and rectangle centres of every (agent, t) (State ctor, motion_planning.h:115-132) ----
+  const size_t NN = (size_t)Na * Nt;
+  C.Na = Na;
+  C.Nt = (int)Nt;
+  for (std::vector<float>* a_ : {&C.xf, &C.yf, &C.xr, &C.yr, &C.xc, &C.yc, &C.cs, &C.sn}) a_->resize(NN);
+  std::vector<float>&xf = C.xf, &yf = C.yf, &xr = C.xr, &yr = C.yr, &xc = C.xc, &yc = C.yc, &cs = C.cs, &sn = C.sn;
+  const float c2r = (v.LF + v.LB) / 2 - v.LB;
+  prc = parallel_for(Na, HOST_THREADS_PER_WORLD, [&](const int a) {
     double* g = out->x0_bar + (size_t)a * Nt * 6;
     const size_t xs = X[a].size();
     for (size_t i = 0; i < Nt; ++i) {
@@ -160,27 +182,20 @@ int bridge_interpolate(const double* states, const int32_t* actions, const int32
       g[i * 6 + 4] = ((g[(i + 1) * 6] - g[i * 6]) / dt) * std::cos(yaw) + ((g[(i + 1) * 6 + 1] - g[i * 6 + 1]) / dt) * std::sin(yaw);
       g[i * 6 + 5] = (g[(i + 1) * 6 + 3] - g[i * 6 + 3]) / dt;
     }
-  }
-
-  // ---- float disc centres and rectangle centres of every (agent, t) (State ctor, motion_planning.h:115-132) ----
-  const size_t NN = (size_t)Na * Nt;
-  C.Na = Na;
-  C.Nt = (int)Nt;
-  for (std::vector<float>* a_ : {&C.xf, &C.yf, &C.xr, &C.yr, &C.xc, &C.yc, &C.cs, &C.sn}) a_->assign(NN, 0.f);
-  std::vector<float>&xf = C.xf, &yf = C.yf, &xr = C.xr, &yr = C.yr, &xc = C.xc, &yc = C.yc, &cs = C.cs, &sn = C.sn;
-  const float c2r = (v.LF + v.LB) / 2 - v.LB;
-  for (size_t k = 0; k < NN; ++k) {
-    const double x = out->x0_bar[k * 6], y = out->x0_bar[k * 6 + 1], yaw = out->x0_bar[k * 6 + 2];
-    const double c = std::cos(yaw), s = std::sin(yaw);
-    xf[k] = (float)(x + v.f2x * c);
-    xr[k] = (float)(x + v.r2x * c);
-    yf[k] = (float)(y + v.f2x * s);
-    yr[k] = (float)(y + v.r2x * s);
-    xc[k] = (float)(x + c2r * c);
-    yc[k] = (float)(y + c2r * s);
-    cs[k] = (float)c;
-    sn[k] = (float)s;
-  }
+    for (size_t k = (size_t)a * Nt; k < (size_t)(a + 1) * Nt; ++k) {
+      const double x = out->x0_bar[k * 6], y = out->x0_bar[k * 6 + 1], yaw = out->x0_bar[k * 6 + 2];
+      const double c = std::cos(yaw), s = std::sin(yaw);
+      xf[k] = (float)(x + v.f2x * c);
+      xr[k] = (float)(x + v.r2x * c);
+      yf[k] = (float)(y + v.f2x * s);
+      yr[k] = (float)(y + v.r2x * s);
+      xc[k] = (float)(x + c2r * c);
+      yc[k] = (float)(y + c2r * s);
+      cs[k] = (float)c;
+      sn[k] = (float)s;
+    }
+  });
+  if (prc != CSDO_OK) return prc;
 
   return CSDO_OK;
 }
@@ -196,8 +211,7 @@ bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* ve
   parm_.r_trust = r_trust;
   const csdo_qp_parm* parm = &parm_;
   pairs.clear();
-  // ---- neighbour pairs (findNeighborPairsByTrustRegion :12-49), order (t, i, j) ----
-  bool legal = true;
+  // ---- neighbour pairs (findNeighborPairsByTrustRegion :12-49), order (t, i, j): blocks of timesteps side by side ----
   const double reach = 2 * std::sqrt(2) * parm->r_trust;
   const float length = v.LF + v.LB, width = v.W;
   // A pair whose rectangle centres are further apart than the reach plus what the four disc centres can lie off the rectangle centres
@@ -207,7 +221,13 @@ bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* ve
   const double c2r = (double)((v.LF + v.LB) / 2 - v.LB);
   const double off = std::max(std::fabs((double)v.f2x - c2r), std::fabs((double)v.r2x - c2r));
   const double far2 = (reach + 2.0 * off + 1e-3) * (reach + 2.0 * off + 1e-3);
-  for (size_t t = 0; t < Nt; ++t)
+  constexpr size_t T_BLOCK = 16;
+  const int n_blocks = (int)((Nt + T_BLOCK - 1) / T_BLOCK);
+  std::vector<std::vector<int32_t>> found((size_t)n_blocks);
+  std::atomic<int> illegal{0};
+  const int prc = parallel_for(n_blocks, HOST_THREADS_PER_WORLD, [&](const int blk) {
+   std::vector<int32_t>& mine = found[(size_t)blk];
+   for (size_t t = (size_t)blk * T_BLOCK; t < std::min(Nt, (size_t)(blk + 1) * T_BLOCK); ++t)
     for (int i = 0; i < Na - 1; ++i) {
       const size_t ki = (size_t)i * Nt + t;
       for (int j = i + 1; j < Na; ++j) {
@@ -221,9 +241,9 @@ bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* ve
         d2 = std::min(d2, sq(xr[ki], xf[kj]) + sq(yr[ki], yf[kj]));
         d2 = std::min(d2, sq(xr[ki], xr[kj]) + sq(yr[ki], yr[kj]));
         if (!(std::sqrt(d2) < reach)) continue;
-        pairs.push_back((int32_t)t);
-        pairs.push_back(i);
-        pairs.push_back(j);
+        mine.push_back((int32_t)t);
+        mine.push_back(i);
+        mine.push_back(j);
         // rectangle SAT in float (State::agentCollision, motion_planning.h:140-183)
         const float sx = xc[kj] - xc[ki], sy = yc[kj] - yc[ki];
         const float cv = cs[ki], sv = sn[ki], co = cs[kj], so = sn[kj];
@@ -234,9 +254,16 @@ bool bridge_pairs(const BridgeCentres& C, double r_trust, const csdo_vehicle* ve
                          (std::fabs(sx * sv - sy * cv) <= std::fabs(dx3 * sv - dy3 * cv) + std::fabs(dx4 * sv - dy4 * cv) + hw) &&
                          (std::fabs(sx * co + sy * so) <= std::fabs(dx1 * co + dy1 * so) + std::fabs(dx2 * co + dy2 * so) + hl) &&
                          (std::fabs(sx * so - sy * co) <= std::fabs(dx1 * so - dy1 * co) + std::fabs(dx2 * so - dy2 * co) + hw);
-        if (hit) legal = false;
+        if (hit) illegal.store(1, std::memory_order_relaxed);
       }
     }
+  });
+  if (prc != CSDO_OK) throw std::bad_alloc();   // a block's list could not grow: the callers (capi.hip) return CSDO_ENOMEM
+  size_t total = 0;
+  for (const auto& f : found) total += f.size();
+  pairs.reserve(total);
+  for (const auto& f : found) pairs.insert(pairs.end(), f.begin(), f.end());
+  const bool legal = illegal.load() == 0;
 
   return legal;
 }
@@ -273,15 +300,22 @@ int bridge_planes(const BridgeCentres& C, const int32_t* pairs, size_t n_pairs_i
   }
   std::memcpy(out->plane_off, cnt.data(), sizeof(int32_t) * (Na + 1));
   if (n_pairs) std::memcpy(out->pairs, pairs, sizeof(int32_t) * 3 * (size_t)n_pairs);
-  std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
-  const double rv = v.rv;
+  // the slot of every pair in its two agents' lists (pair order), then the coefficients in blocks of pairs side by side
+  std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1), slot((size_t)2 * std::max(n_pairs, 1));
   for (int p = 0; p < n_pairs; ++p) {
+    slot[2 * (size_t)p] = fill[pairs[3 * p + 1]]++;
+    slot[2 * (size_t)p + 1] = fill[pairs[3 * p + 2]]++;
+  }
+  const double rv = v.rv;
+  constexpr int P_BLOCK = 256;
+  (void)parallel_for((n_pairs + P_BLOCK - 1) / P_BLOCK, HOST_THREADS_PER_WORLD, [&](const int blk) {
+   for (int p = blk * P_BLOCK; p < std::min(n_pairs, (blk + 1) * P_BLOCK); ++p) {
     const int t = pairs[3 * p], i = pairs[3 * p + 1], j = pairs[3 * p + 2];
     const size_t ki = (size_t)i * Nt + t, kj = (size_t)j * Nt + t;
     const double Pi[2][2] = {{xf[ki], yf[ki]}, {xr[ki], yr[ki]}};  // own front, own rear
     const double Pj[2][2] = {{xf[kj], yf[kj]}, {xr[kj], yr[kj]}};
-    csdo_plane& pi = out->planes[fill[i]++];
-    csdo_plane& pj = out->planes[fill[j]++];
+    csdo_plane& pi = out->planes[slot[2 * (size_t)p]];
+    csdo_plane& pj = out->planes[slot[2 * (size_t)p + 1]];
     pi.t = pj.t = t;
     if (coef) {
       std::memcpy(pi.c, coef + (size_t)p * 24, sizeof(pi.c));
@@ -304,7 +338,8 @@ int bridge_planes(const BridgeCentres& C, const int32_t* pairs, size_t n_pairs_i
         pj.c[3 * slot_j + 1] = -b;
         pj.c[3 * slot_j + 2] = -c_j;
       }
-  }
+   }
+  });
   out->n_pairs = n_pairs;
   return CSDO_OK;
 }

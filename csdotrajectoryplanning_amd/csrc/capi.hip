@@ -91,6 +91,9 @@ struct csdo_handle_s {
   // launch groups (dsqp_launch.h): group 0 runs on the caller's stream, the others concurrently on side streams
   std::vector<LaunchGroup> groups;
   int min_mode = 0;            // csdo_dsqp_set_min_residency_mode
+  bool host_results = false;   // csdo_dsqp_set_host_results: the kernels write results and counters into stage_down (page-locked host
+                               // memory, mapped into the device's address space) instead of sol / corr / sqp / ...: nothing is left to copy
+  bool results_in_stage = false;   // ... what the uploaded batch was set up with
   int n_cu = 256;              // compute units of the device: persistent workgroups per launch group
   std::vector<int32_t> order;
   std::vector<hipStream_t> side;
@@ -120,6 +123,24 @@ struct csdo_handle_s {
   hipStream_t four[4] = {nullptr, nullptr, nullptr, nullptr};   // ... the owner's four streams
   bool run_pending = false;    // csdo_dsqp_run_async has been called and csdo_dsqp_wait has not
   std::vector<char> pending_second;   // which groups of the pending run have a second launch
+};
+
+// where the results of a batch lie in stage_down: sol [steps][6], corr [steps][8], four int32 per agent, ticks int64 per agent
+struct ResultLayout {
+  size_t b_sol, b_corr, o_corr, o_sqp, o_admm, o_stat, o_legal, o_ticks, total;
+  explicit ResultLayout(const HostBatch& hb) {
+    const size_t Na = hb.agents.size();
+    b_sol = (size_t)hb.steps_total * 6 * sizeof(double);
+    b_corr = (size_t)hb.steps_total * 8 * sizeof(double);
+    const size_t b_i32 = (Na * sizeof(int32_t) + 255) & ~(size_t)255;
+    o_corr = (b_sol + 255) & ~(size_t)255;
+    o_sqp = o_corr + ((b_corr + 255) & ~(size_t)255);
+    o_admm = o_sqp + b_i32;
+    o_stat = o_admm + b_i32;
+    o_legal = o_stat + b_i32;
+    o_ticks = o_legal + b_i32;
+    total = o_ticks + Na * sizeof(int64_t);
+  }
 };
 
 #define HIP_OK(expr, code)                 \
@@ -724,7 +745,24 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   h->limit_world = h->limit_agent = -1;
   h->limit_bytes = 0;
   const double t0 = now_s();
-  int rc = pack_worlds(worlds, n_worlds, h->hb);
+  // Everything the kernels read goes into ONE page-locked arena (256-byte aligned slots: agents, worlds, x0, planes, tstart, obstacles,
+  // order) and from there to the device in one copy.  The four big arrays are packed straight into their slots (pack_worlds' placer).
+  size_t total = 0;
+  const PackPlacer place = [&](const PackSizes& n, PackPlace& at) -> int {
+    const size_t bytes[7] = {n.agents * sizeof(AgentDesc), n.worlds * sizeof(WorldDesc), n.x0 * sizeof(double), n.planes * sizeof(PlaneDev),
+                             n.tstart * sizeof(int32_t), n.obstacles * sizeof(double), n.agents * sizeof(int32_t)};
+    total = 0;
+    for (int k = 0; k < 7; ++k) {
+      h->in_off[k] = total;
+      total += (bytes[k] + 255) & ~(size_t)255;
+    }
+    const int prc = h->stage_up.ensure(total);
+    if (prc != CSDO_OK) return prc;
+    char* st = (char*)h->stage_up.p;
+    at = PackPlace{(double*)(st + h->in_off[2]), (PlaneDev*)(st + h->in_off[3]), (int32_t*)(st + h->in_off[4]), (double*)(st + h->in_off[5])};
+    return CSDO_OK;
+  };
+  int rc = pack_worlds(worlds, n_worlds, h->hb, &place);
   if (rc == CSDO_ELIMIT) note_horizon_limit(h, worlds, n_worlds);
   if (rc != CSDO_OK) return rc;
   HostBatch& hb = h->hb;
@@ -749,55 +787,11 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
       return CSDO_ELIMIT;
     }
   const double t1 = now_s();
-  // stage everything in one page-locked arena (256-byte aligned slots), then one asynchronous copy per array
-  struct Item { const void* src; size_t bytes; size_t off; };
-  Item items[] = {{hb.agents.data(), hb.agents.size() * sizeof(AgentDesc), 0},
-                  {hb.worlds.data(), hb.worlds.size() * sizeof(WorldDesc), 0},
-                  {hb.x0.data(), hb.x0.size() * sizeof(double), 0},
-                  {hb.planes.data(), hb.planes.size() * sizeof(PlaneDev), 0},
-                  {hb.tstart.data(), hb.tstart.size() * sizeof(int32_t), 0},
-                  {hb.obstacles.data(), hb.obstacles.size() * sizeof(double), 0},
-                  {h->order.data(), h->order.size() * sizeof(int32_t), 0}};
-  size_t total = 0;
-  for (int k = 0; k < 7; ++k) {
-    items[k].off = h->in_off[k] = total;
-    total += (items[k].bytes + 255) & ~(size_t)255;
-  }
-  if ((rc = h->stage_up.ensure(total)) != CSDO_OK) return rc;
-  {
-    // the big arrays (planes, x0) are copied by a few threads: a single memcpy stream does not reach the DRAM rate.  A thread
-    // that cannot be had (std::system_error under a cgroup's thread limit) copies its piece inline, and nothing unwinds through
-    // a joinable thread.
-    struct Joiner {
-      std::vector<std::thread> t;
-      ~Joiner() {
-        for (auto& x : t)
-          if (x.joinable()) x.join();
-      }
-    } pool;
-    for (Item& it : items) {
-      if (!it.bytes) continue;
-      char* dst = (char*)h->stage_up.p + it.off;
-      const char* src = (const char*)it.src;
-      const size_t chunk = (size_t)4 << 20;
-      if (it.bytes <= chunk) {
-        std::memcpy(dst, src, it.bytes);
-      } else {
-        const int parts = (int)std::min<size_t>(8, (it.bytes + chunk - 1) / chunk);
-        const size_t per = ((it.bytes + parts - 1) / parts + 63) & ~(size_t)63;
-        for (int k = 0; k < parts; ++k) {
-          const size_t lo = (size_t)k * per, hi = std::min(it.bytes, lo + per);
-          if (lo >= hi) continue;
-          try {
-            pool.t.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
-          } catch (...) {
-            std::memcpy(dst + lo, src + lo, hi - lo);
-          }
-        }
-      }
-    }
-    for (auto& t : pool.t) t.join();
-    pool.t.clear();
+  {   // the small arrays: descriptors (build_groups has set the agents' classes) and the launch order
+    char* st = (char*)h->stage_up.p;
+    std::memcpy(st + h->in_off[0], hb.agents.data(), hb.agents.size() * sizeof(AgentDesc));
+    std::memcpy(st + h->in_off[1], hb.worlds.data(), hb.worlds.size() * sizeof(WorldDesc));
+    std::memcpy(st + h->in_off[6], h->order.data(), h->order.size() * sizeof(int32_t));
   }
   const double t2 = now_s();
   if ((rc = h->in_arena.ensure(total)) != CSDO_OK) return rc;
@@ -842,13 +836,23 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   }
   if ((rc = h->rows_ws.ensure((size_t)hb.rows_total * ROWS_WS_STRIDE * sizeof(double))) != CSDO_OK) return rc;
   if ((rc = h->fac_ws.ensure((size_t)hb.fac_total * sizeof(double))) != CSDO_OK) return rc;
-  if ((rc = h->sol.ensure((size_t)hb.steps_total * 6 * sizeof(double))) != CSDO_OK) return rc;
-  if ((rc = h->corr.ensure((size_t)hb.steps_total * 8 * sizeof(double))) != CSDO_OK) return rc;
-  if ((rc = h->sqp.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
-  if ((rc = h->admm.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
-  if ((rc = h->stat.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
-  if ((rc = h->legal.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
-  if ((rc = h->ticks.ensure(Na * sizeof(int64_t))) != CSDO_OK) return rc;
+  const ResultLayout RL(hb);
+  char* res_host = nullptr;   // device address of stage_down when the kernels write there
+  if (h->host_results) {
+    if ((rc = h->stage_down.ensure(RL.total)) != CSDO_OK) return rc;
+    void* dp = nullptr;
+    HIP_OK(hipHostGetDevicePointer(&dp, h->stage_down.p, 0), CSDO_EDEVICE);
+    res_host = (char*)dp;
+  } else {
+    if ((rc = h->sol.ensure(RL.b_sol)) != CSDO_OK) return rc;
+    if ((rc = h->corr.ensure(RL.b_corr)) != CSDO_OK) return rc;
+    if ((rc = h->sqp.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+    if ((rc = h->admm.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+    if ((rc = h->stat.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+    if ((rc = h->legal.ensure(Na * sizeof(int32_t))) != CSDO_OK) return rc;
+    if ((rc = h->ticks.ensure(Na * sizeof(int64_t))) != CSDO_OK) return rc;
+  }
+  h->results_in_stage = h->host_results;
   DeviceBatch& B = h->dev;
   const char* const in = (const char*)h->in_arena.p;
   B.agents = (const AgentDesc*)(in + h->in_off[0]);
@@ -859,13 +863,13 @@ static int upload_impl(csdo_handle h, const csdo_problem* worlds, int32_t n_worl
   B.obstacles = (const double*)(in + h->in_off[5]);
   B.rows_ws = (double*)h->rows_ws.p;
   B.fac_ws = (double*)h->fac_ws.p;
-  B.sol = (double*)h->sol.p;
-  B.corr = (double*)h->corr.p;
-  B.sqp_iters = (int32_t*)h->sqp.p;
-  B.admm_iters = (int32_t*)h->admm.p;
-  B.last_status = (int32_t*)h->stat.p;
-  B.static_legal = (int32_t*)h->legal.p;
-  B.agent_ticks = (int64_t*)h->ticks.p;
+  B.sol = res_host ? (double*)res_host : (double*)h->sol.p;
+  B.corr = res_host ? (double*)(res_host + RL.o_corr) : (double*)h->corr.p;
+  B.sqp_iters = res_host ? (int32_t*)(res_host + RL.o_sqp) : (int32_t*)h->sqp.p;
+  B.admm_iters = res_host ? (int32_t*)(res_host + RL.o_admm) : (int32_t*)h->admm.p;
+  B.last_status = res_host ? (int32_t*)(res_host + RL.o_stat) : (int32_t*)h->stat.p;
+  B.static_legal = res_host ? (int32_t*)(res_host + RL.o_legal) : (int32_t*)h->legal.p;
+  B.agent_ticks = res_host ? (int64_t*)(res_host + RL.o_ticks) : (int64_t*)h->ticks.p;
   B.order = (const int32_t*)(in + h->in_off[6]);
   B.n_agents = (int32_t)Na;
   B.prof = nullptr;
@@ -990,6 +994,14 @@ int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_age
   return CSDO_OK;
 }
 
+int csdo_dsqp_set_host_results(csdo_handle h, int32_t on) {
+  if (!h) return CSDO_EINVAL;
+  if (h->multi)
+    for (csdo_handle kid : h->multi->kids) kid->host_results = on != 0;
+  h->host_results = on != 0;
+  return CSDO_OK;
+}
+
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode) {
   if (!h || mode < 0 || mode > 3) return CSDO_EINVAL;
   if (h->multi)
@@ -1026,7 +1038,7 @@ int32_t csdo_dsqp_launch_groups(csdo_handle h, csdo_launch_group* out, int32_t c
 void* csdo_dsqp_device_solutions(csdo_handle h, int64_t* n_doubles) {
   if (!h || !h->uploaded || h->multi) return nullptr;   // (several devices: ask the children, csdo_dsqp_multi_child)
   if (n_doubles) *n_doubles = h->hb.steps_total * 6;
-  return h->sol.p;
+  return h->dev.sol;   // (csdo_dsqp_set_host_results: the device address of page-locked host memory)
 }
 
 int csdo_dsqp_download(csdo_handle h, csdo_result* results, int32_t n_worlds) {
@@ -1039,22 +1051,22 @@ static int download_impl(csdo_handle h, csdo_result* results, int32_t n_worlds) 
   const HostBatch& hb = h->hb;
   const size_t Na = hb.agents.size();
   const double t0 = now_s();
-  const size_t b_sol = (size_t)hb.steps_total * 6 * sizeof(double), b_corr = (size_t)hb.steps_total * 8 * sizeof(double);
-  const size_t b_i32 = (Na * sizeof(int32_t) + 255) & ~(size_t)255, b_i64 = Na * sizeof(int64_t);
-  const size_t o_corr = (b_sol + 255) & ~(size_t)255, o_sqp = o_corr + ((b_corr + 255) & ~(size_t)255);
-  const size_t o_admm = o_sqp + b_i32, o_stat = o_admm + b_i32, o_legal = o_stat + b_i32, o_ticks = o_legal + b_i32;
+  const ResultLayout RL(hb);
+  const size_t o_corr = RL.o_corr, o_sqp = RL.o_sqp, o_admm = RL.o_admm, o_stat = RL.o_stat, o_legal = RL.o_legal, o_ticks = RL.o_ticks;
   int rc;
-  if ((rc = h->stage_down.ensure(o_ticks + b_i64)) != CSDO_OK) return rc;
+  if ((rc = h->stage_down.ensure(RL.total)) != CSDO_OK) return rc;   // (host results: no-op, the upload sized it)
   char* st = (char*)h->stage_down.p;
-  hipStream_t s = h->copy;   // (the solve is over - csdo_dsqp_wait has returned -, so nothing orders this copy but itself)
-  HIP_OK(hipMemcpyAsync(st, h->sol.p, b_sol, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(st + o_corr, h->corr.p, b_corr, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(st + o_sqp, h->sqp.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(st + o_admm, h->admm.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(st + o_stat, h->stat.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(st + o_legal, h->legal.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipMemcpyAsync(st + o_ticks, h->ticks.p, b_i64, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
-  HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
+  if (!h->results_in_stage) {
+    hipStream_t s = h->copy;   // (the solve is over - csdo_dsqp_wait has returned -, so nothing orders this copy but itself)
+    HIP_OK(hipMemcpyAsync(st, h->sol.p, RL.b_sol, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipMemcpyAsync(st + o_corr, h->corr.p, RL.b_corr, hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipMemcpyAsync(st + o_sqp, h->sqp.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipMemcpyAsync(st + o_admm, h->admm.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipMemcpyAsync(st + o_stat, h->stat.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipMemcpyAsync(st + o_legal, h->legal.p, Na * sizeof(int32_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipMemcpyAsync(st + o_ticks, h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost, s), CSDO_EDEVICE);
+    HIP_OK(hipStreamSynchronize(s), CSDO_EDEVICE);
+  }
   const double t1 = now_s();
   const int64_t* h_ticks = (const int64_t*)(st + o_ticks);
   unpack_results(hb, nullptr, n_worlds, (const double*)st, (const double*)(st + o_corr), (const int32_t*)(st + o_sqp),
@@ -1228,7 +1240,7 @@ int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* 
     std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
     // (parallel_for, batch_pack.h: a body that throws or a thread that cannot be created never unwinds through joinable threads)
     auto pool = [&](auto&& body) {
-      if (parallel_for(n_worlds, 16, body) != CSDO_OK)
+      if (parallel_for(n_worlds, 64, body) != CSDO_OK)
         for (int w = 0; w < n_worlds; ++w)
           if (rcs[w] == CSDO_OK) rcs[w] = CSDO_ENOMEM;
     };
@@ -1338,7 +1350,7 @@ int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const i
   for (int w = 0; w < n_worlds; ++w) std::memset(&outs[w], 0, sizeof(csdo_bridge_out));   // before anything can throw
   try {
     std::vector<int> rcs((size_t)n_worlds, CSDO_OK);
-    int rc = parallel_for(n_worlds, 16, [&](int w) {
+    int rc = parallel_for(n_worlds, 64, [&](int w) {
       rcs[w] = bridge_preprocess(states[w], actions[w], path_off[w], Na[w], goals[w], veh, parm, &outs[w]);
     });
     for (int w = 0; w < n_worlds && rc == CSDO_OK; ++w) rc = rcs[w];
@@ -1475,7 +1487,7 @@ int csdo_debug_phase_ticks(csdo_handle h, int64_t* phases16, int64_t* agent_tick
   if (!h || h->multi || !h->uploaded) return CSDO_EINVAL;
   const size_t Na = h->hb.agents.size();
   if (hipMemcpy(phases16, h->prof.p, Na * 48 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
-  if (hipMemcpy(agent_ticks, h->ticks.p, Na * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
+  if (hipMemcpy(agent_ticks, h->dev.agent_ticks, Na * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return CSDO_EDEVICE;
   return CSDO_OK;
 }
 #endif

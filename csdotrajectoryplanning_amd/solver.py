@@ -92,7 +92,7 @@ class DsqpHandle:
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
 
     def do_phase_stream(self, items, veh, parm, fractions=(0.08, 0.27, 0.65), out=None, order=None, single_launch_if_mixed=True,
-                        min_first_agents=230):
+                        min_first_agents=230, host_results=True):
         """The DO phase of csdo.cc:111-148 for a batch of worlds, streamed in chunks of worlds: the host bridge, the packing
         and the H2D copies of chunk k + 1 run under the solve of chunk k (csdo_dsqp_create_shared / csdo_dsqp_run_async), the
         results of a chunk come back under the solve of the later ones.  The chunks grow (a small first one starts the GPU
@@ -103,6 +103,7 @@ class DsqpHandle:
         single_launch_if_mixed: a job whose first chunk needs more than one kernel class is solved by ONE launch of all its
         worlds on this handle instead (which replaces the batch this handle held).
         min_first_agents: the first chunk is enlarged until it holds that many agents (0: the fractions as given).
+        host_results: the chunks' kernels write their results into page-locked host memory (csdo_dsqp_set_host_results).
         Returns (solutions in the order of `items`, dict of host-side timings in seconds)."""
         import time
         n = len(items)
@@ -124,7 +125,11 @@ class DsqpHandle:
             tb = time.perf_counter()
             bridged = self.interpolate_and_planes_batch([items[i] for i in idx], veh, parm)
             tu = time.perf_counter()
-            self.upload([b[0] for b in bridged])
+            self.set_host_results(host_results)
+            try:
+                self.upload([b[0] for b in bridged])
+            finally:
+                self.set_host_results(False)          # (this handle's later uploads: the default again)
             tr = time.perf_counter()
             kern = self.run()
             kernel_end = time.perf_counter() - t0
@@ -141,6 +146,7 @@ class DsqpHandle:
             for c in range(len(fr)):
                 part = idx[cuts[c]:cuts[c + 1]]
                 hc = self.shared(c)
+                hc.set_host_results(host_results)   # the last chunk's D2H copy is the one that nothing hides
                 tb = time.perf_counter()
                 bridged = interpolate_and_planes_batch_host([items[i] for i in part], veh, parm)
                 tu = time.perf_counter()
@@ -157,7 +163,11 @@ class DsqpHandle:
                     rest = idx[cuts[1]:]
                     more = interpolate_and_planes_batch_host([items[i] for i in rest], veh, parm) if rest else []
                     tu2 = time.perf_counter()
-                    self.upload([b[0] for b in bridged] + [b[0] for b in more])
+                    self.set_host_results(host_results)
+                    try:
+                        self.upload([b[0] for b in bridged] + [b[0] for b in more])
+                    finally:
+                        self.set_host_results(False)
                     tr2 = time.perf_counter()
                     kern = self.run()
                     kernel_end = time.perf_counter() - t0
@@ -204,6 +214,10 @@ class DsqpHandle:
         out = (C.c_double * 5)()
         check(lib().csdo_dsqp_last_transfer_seconds(self._h, C.byref(out)), "csdo_dsqp_last_transfer_seconds")
         return dict(zip(("pack", "stage", "h2d", "d2h", "unpack"), [float(v) for v in out]))
+
+    def set_host_results(self, on=True):
+        """csdo_dsqp_set_host_results: from the next upload on the kernels write their results into page-locked host memory."""
+        check(lib().csdo_dsqp_set_host_results(self._h, int(bool(on))), "csdo_dsqp_set_host_results")
 
     def set_min_residency_mode(self, mode):
         check(lib().csdo_dsqp_set_min_residency_mode(self._h, int(mode)), "csdo_dsqp_set_min_residency_mode")

@@ -230,6 +230,12 @@ int csdo_dsqp_agent_groups(csdo_handle h, int32_t* group_of_agent, int32_t n_age
  * change the speed only (modes 0, 1 and 2 run the same pair-split solve: same bits); level 3 moves agents of the 768-thread class
  * from the pair-split solve to the one-lane form of mode 3, which sums a node's partials in another order: last bits differ. */
 int csdo_dsqp_set_min_residency_mode(csdo_handle h, int32_t mode);
+/* Where the kernels put their results, from the next upload on.  0 (default): device memory; csdo_dsqp_download copies them out
+ * (57 MB for 3000 vehicles: 1 ms of PCIe behind the last kernel).  1: page-locked host memory mapped into the device's address space
+ * - every workgroup writes its agent's trajectory, safe boxes and counters across PCIe when the agent is done, under the other
+ * agents' iterations; csdo_dsqp_download then has nothing to copy, only to scatter into the caller's arrays.  Same values either way.
+ * csdo_dsqp_device_solutions returns that memory's device address (a collective reading it reads across PCIe: keep 0 there). */
+int csdo_dsqp_set_host_results(csdo_handle h, int32_t on);
 /* The launcher's relative work estimate per agent (the quantity the launch order and the CU shares of the groups come
  * from: horizon, plane count and how much of the initial guess sits in tight spots), in upload order; host code, no GPU
  * needed.  For sharding a batch over GPUs by work instead of by agent count. */

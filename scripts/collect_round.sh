@@ -14,9 +14,13 @@ done
 [ -f gpurun_out/$TAG/stream_map100.txt ] && grep -v amdgpu gpurun_out/$TAG/stream_map100.txt > profiles/${TAG}_stream_map100.txt
 [ -f gpurun_out/$TAG/single_instance_times.txt ] && grep -v amdgpu gpurun_out/$TAG/single_instance_times.txt > profiles/${TAG}_single_instance_times.txt
 [ -f gpurun_out/$TAG/host_info.txt ] && cp gpurun_out/$TAG/host_info.txt profiles/${TAG}_host_info.txt
-[ -f gpurun_out/$TAG/phases_map100.txt ] && cp gpurun_out/$TAG/phases_map100.txt profiles/${TAG}_phase_profile_map100.txt
-[ -f gpurun_out/$TAG/phases_map50.txt ] && cp gpurun_out/$TAG/phases_map50.txt profiles/${TAG}_phase_profile_map50.txt
-[ -f gpurun_out/$TAG/phases_room50_long.txt ] && cp gpurun_out/$TAG/phases_room50_long.txt profiles/${TAG}_phase_profile_room50_long_horizons.txt
+# (a phase profile is a table, not an error message: a stale libcsdo_hip_prof.so - `make -C csdotrajectoryplanning_amd/csrc prof` after every
+#  change of the sources - leaves a load error in the file, which is not copied)
+for pair in phases_map100:phase_profile_map100 phases_map50:phase_profile_map50 phases_room50_long:phase_profile_room50_long_horizons; do
+  f=gpurun_out/$TAG/${pair%%:*}.txt
+  [ -f $f ] || continue
+  if grep -q "Traceback\|Error" $f; then echo "NOT collected (failed run): $f"; else cp $f profiles/${TAG}_${pair#*:}.txt; fi
+done
 [ -f gpurun_out/$TAG/group_times_room50.txt ] && grep -v amdgpu gpurun_out/$TAG/group_times_room50.txt > profiles/${TAG}_group_times_room50.txt
 grep -E "passed|failed" gpurun_out/$TAG/pytest.log | tail -1 > profiles/${TAG}_pytest_gpu_summary.txt
 grep -E "^PASSED|^FAILED" gpurun_out/$TAG/pytest.log >> profiles/${TAG}_pytest_gpu_summary.txt

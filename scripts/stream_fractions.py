@@ -18,14 +18,18 @@ h.upload([w for w, _ in built])
 h.run()
 print("resident batch: kernels %.1f ms" % (min(h.run() for _ in range(3)) * 1e3))
 for fr in sets.split(";"):
+    hr_set = (True,)
+    if fr.endswith("!"):          # "...!": with the results in device memory too (csdo_dsqp_set_host_results off)
+        fr, hr_set = fr[:-1], (False, True)
     f = tuple(float(x) for x in fr.split(","))
-    out, best = None, None
-    for _ in range(5):
-        out, tm = h.do_phase_stream(items, w0.veh, w0.parm, fractions=f, out=out, min_first_agents=0)
-        if best is None or tm["total"] < best["total"]:
-            best = tm
-    print("%-24s total %.1f ms  first launch %.1f  kernels done %.1f  chunks %s" % (
-        fr, best["total"] * 1e3, best["first_launch"] * 1e3, best["kernels_done"] * 1e3,
-        [(c["worlds"], round(c["kernel"] * 1e3, 1)) for c in best["chunks"]]))
-    print("   upload of the chunks, ms:", [(round(c["upload"] * 1e3, 1), {k: round(v * 1e3, 1) for k, v in c.get("upload_parts", {}).items() if k in ("pack", "stage", "h2d")}) for c in best["chunks"]])
+    for hr in hr_set:
+        out, best = None, None
+        for _ in range(6):
+            out, tm = h.do_phase_stream(items, w0.veh, w0.parm, fractions=f, out=out, min_first_agents=0, host_results=hr)
+            if best is None or tm["total"] < best["total"]:
+                best = tm
+        print("%-24s %s total %.1f ms  first launch %.1f  kernels done %.1f  chunks %s" % (
+            fr, "results -> host memory  " if hr else "results -> device memory", best["total"] * 1e3, best["first_launch"] * 1e3, best["kernels_done"] * 1e3,
+            [(c["worlds"], round(c["kernel"] * 1e3, 1)) for c in best["chunks"]]))
+        print("   bridge / upload of the chunks, ms:", [(round(c["bridge"] * 1e3, 2), round(c["upload"] * 1e3, 2), {k: round(v * 1e3, 2) for k, v in c.get("upload_parts", {}).items() if k in ("pack", "stage", "h2d")}) for c in best["chunks"]])
 h.close()

@@ -65,6 +65,29 @@ def test_streamed_do_phase_returns_the_bits_of_the_batch(gpu_handle):
     assert all(_same(g, r) for g, r in zip(got100, ref100)) and [c["worlds"] for c in tm100["chunks"]] == [4]
 
 
+def test_results_written_to_host_memory_are_the_results_copied_from_device_memory(gpu_handle):
+    """csdo_dsqp_set_host_results: the kernels write trajectories, safe boxes and counters into page-locked host memory (nothing
+    left to copy behind the last kernel - what do_phase_stream does by default) or into device memory: the same bits, on a plain
+    handle, on the streamed chunks, switched on and off between uploads, and the per-agent device times arrive as well."""
+    items, worlds = _items_and_worlds("map100", 4)
+    ref = gpu_handle.solve_batch(worlds)
+    try:
+        gpu_handle.set_host_results(True)
+        got = gpu_handle.solve_batch(worlds)
+        assert all(_same(g, r) for g, r in zip(got, ref))
+        assert all(g.t_max_individual > 0.0 for g in got)
+        assert gpu_handle.transfer_seconds()["d2h"] < 2e-5            # nothing copied: the timer brackets an empty branch
+        small = gpu_handle.solve_batch(worlds[1:2])           # a smaller batch in the same page-locked block
+        assert _same(small[0], ref[1])
+    finally:
+        gpu_handle.set_host_results(False)
+    again = gpu_handle.solve_batch(worlds)
+    assert all(_same(g, r) for g, r in zip(again, ref)) and gpu_handle.transfer_seconds()["d2h"] > 0.0
+    for hr in (True, False):
+        got_s, tm = gpu_handle.do_phase_stream(items, worlds[0].veh, worlds[0].parm, min_first_agents=0, host_results=hr)
+        assert tm["streamed"] is True and all(_same(g, r) for g, r in zip(got_s, ref))
+
+
 def test_run_async_wait_and_their_guards(gpu_handle):
     from csdotrajectoryplanning_amd._lib import CsdoError
     _, worlds = _items_and_worlds("map50", 2)

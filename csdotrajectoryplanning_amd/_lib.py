@@ -56,6 +56,11 @@ def lib():
         L.csdo_dsqp_launch_groups.restype = C.c_int32
         L.csdo_dsqp_set_min_residency_mode.argtypes = [H, C.c_int32]
         L.csdo_dsqp_set_host_results.argtypes = [H, C.c_int32]
+        L.csdo_do_phase.argtypes = [H, C.POINTER(abi.CoarseWorld), C.c_int32, C.POINTER(abi.Vehicle), C.POINTER(abi.QpParm),
+                                    C.POINTER(abi.Result), abi.c_int32_p, C.POINTER(abi.DoPhaseTiming)]
+        L.csdo_do_phase_horizon.argtypes = [abi.c_int32_p, C.c_int32, C.POINTER(abi.QpParm)]
+        L.csdo_do_phase_horizon.restype = C.c_int32
+        L.csdo_do_phase_cuts.argtypes = [abi.c_int32_p, C.c_int32, C.c_int32, abi.c_int32_p]
         L.csdo_dsqp_agent_groups.argtypes = [H, abi.c_int32_p, C.c_int32]
         L.csdo_dsqp_device_solutions.argtypes = [H, C.POINTER(C.c_int64)]
         L.csdo_dsqp_device_solutions.restype = C.c_void_p

@@ -66,6 +66,19 @@ class BridgeOut(C.Structure):
                 ("pairs", c_int32_p)]
 
 
+class CoarseWorld(C.Structure):
+    """csdo_coarse_world (include/csdo_dsqp.h): one world's front-end paths and map, as csdo_do_phase takes them."""
+    _fields_ = [("states", c_double_p), ("actions", c_int32_p), ("path_off", c_int32_p), ("goals", c_double_p),
+                ("obstacles", c_double_p), ("Na", C.c_int32), ("n_obs", C.c_int32), ("dimx", C.c_double), ("dimy", C.c_double)]
+
+
+class DoPhaseTiming(C.Structure):
+    """csdo_do_phase_timing."""
+    _fields_ = [("first_launch", C.c_double), ("kernels_done", C.c_double), ("total", C.c_double),
+                ("n_chunks", C.c_int32), ("streamed", C.c_int32), ("chunk_worlds", C.c_int32 * 4),
+                ("chunk_bridge", C.c_double * 4), ("chunk_upload", C.c_double * 4), ("chunk_kernel", C.c_double * 4)]
+
+
 class FrontEndParm(C.Structure):
     """csdo_front_end_parm (include/csdo_dsqp.h)."""
     _fields_ = [("penalty_turning", C.c_double), ("penalty_reversing", C.c_double), ("penalty_cod", C.c_double),
@@ -102,7 +115,7 @@ class LaunchGroup(C.Structure):
 
 EXPORTED_SYMBOLS = (
     "csdo_dsqp_create", "csdo_dsqp_create_multi", "csdo_dsqp_multi_count", "csdo_dsqp_multi_child", "csdo_dsqp_shard_bounds", "csdo_dsqp_destroy", "csdo_dsqp_solve", "csdo_dsqp_solve_batch", "csdo_dsqp_upload",
-    "csdo_dsqp_run", "csdo_dsqp_run_async", "csdo_dsqp_wait", "csdo_dsqp_create_shared", "csdo_dsqp_set_lane", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_last_transfer_seconds", "csdo_dsqp_launch_groups", "csdo_dsqp_agent_groups", "csdo_dsqp_set_min_residency_mode", "csdo_dsqp_set_host_results",
+    "csdo_dsqp_run", "csdo_dsqp_run_async", "csdo_dsqp_wait", "csdo_dsqp_create_shared", "csdo_dsqp_set_lane", "csdo_dsqp_download", "csdo_dsqp_last_kernel_seconds", "csdo_dsqp_last_transfer_seconds", "csdo_dsqp_launch_groups", "csdo_dsqp_agent_groups", "csdo_dsqp_set_min_residency_mode", "csdo_dsqp_set_host_results", "csdo_do_phase", "csdo_do_phase_horizon", "csdo_do_phase_cuts",
     "csdo_dsqp_device_solutions",
     "csdo_preprocess", "csdo_preprocess_device", "csdo_preprocess_device_batch", "csdo_preprocess_batch", "csdo_dsqp_estimate_work", "csdo_dsqp_agent_class", "csdo_dsqp_last_limit", "csdo_front_end_gate_draws", "csdo_bridge_free", "csdo_validate", "csdo_validate_frames", "csdo_generate_boxes", "csdo_math_eval", "csdo_vehicle_default",
     "csdo_qp_parm_default", "csdo_backend_name", "csdo_source_hash",

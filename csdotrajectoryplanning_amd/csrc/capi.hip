@@ -122,6 +122,7 @@ struct csdo_handle_s {
   bool borrowed = false;       // csdo_dsqp_create_shared: the streams belong to another handle (never destroyed here)
   hipStream_t four[4] = {nullptr, nullptr, nullptr, nullptr};   // ... the owner's four streams
   bool run_pending = false;    // csdo_dsqp_run_async has been called and csdo_dsqp_wait has not
+  csdo_handle stream_kids[4] = {nullptr, nullptr, nullptr, nullptr};   // csdo_do_phase: the chunks' shared handles, made once, gone with this one
   std::vector<char> pending_second;   // which groups of the pending run have a second launch
 };
 
@@ -671,6 +672,10 @@ void csdo_dsqp_destroy(csdo_handle h) {
     delete h->multi;
     delete h;
     return;
+  }
+  for (csdo_handle& kid : h->stream_kids) {
+    if (kid) csdo_dsqp_destroy(kid);
+    kid = nullptr;
   }
   (void)hipSetDevice(h->device);
   if (h->run_pending && h->ev1) (void)hipEventSynchronize(h->ev1);
@@ -1479,6 +1484,212 @@ void csdo_qp_parm_default(const csdo_vehicle* v, csdo_qp_parm* p) {
   p->adaptive_rho_interval = 25;
   p->solve_refinement = 0;
   p->_reserved = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The DO phase of csdo.cc:111-148 for a batch of worlds in ONE call: coarse paths in, trajectories out.
+int32_t csdo_do_phase_horizon(const int32_t* path_off, int32_t Na, const csdo_qp_parm* parm) {
+  if (!path_off || !parm || Na < 1) return CSDO_EINVAL;
+  int longest = 0;
+  for (int a = 0; a < Na; ++a) longest = std::max(longest, path_off[a + 1] - path_off[a]);
+  if (longest < 1) return CSDO_EINVAL;
+  // sqp/inter_agent_cons.cc:320-325: the longest path, num_interpolation points inserted per move
+  return (int32_t)((longest - 1) * (parm->num_interpolation + 1) + 1);
+}
+
+extern "C++" {
+// Chunk boundaries of a streamed DO phase (solver.py: stream_cuts is the same rule, tests/test_do_phase.py holds them together):
+// growing chunks 8 % / 27 % / 65 % of the worlds, the first enlarged until it holds ~230 agents - it has to fill the GPU by itself -,
+// and a job that such a first chunk takes a fifth of is cut in two.
+static std::vector<int> do_phase_cuts(const std::vector<int>& agents_per_world, const int min_first_agents) {
+  const int n = (int)agents_per_world.size();
+  const double fr_all[3] = {0.08, 0.27, 0.65};
+  const int nf = std::min(3, n);
+  const double* fr = fr_all + (3 - nf);
+  double tot = 0.0, acc = 0.0;
+  for (int c = 0; c < nf; ++c) tot += fr[c];
+  std::vector<int> cuts{0};
+  for (int c = 0; c < nf; ++c) {
+    acc += fr[c];
+    const int hi = c == nf - 1 ? n : std::max(cuts.back() + 1, std::min(n - (nf - 1 - c), (int)std::nearbyint(n * acc / tot)));
+    cuts.push_back(hi);
+  }
+  long long run = 0;
+  int fill = n + 1;   // worlds until min_first_agents agents are reached, + 1 (numpy.searchsorted(cumsum, m) + 1)
+  for (int w = 0; w < n; ++w) {
+    run += agents_per_world[w];
+    if (run >= min_first_agents) {
+      fill = w + 1;
+      break;
+    }
+  }
+  if (cuts.size() > 2 && cuts[1] < fill) {
+    if (fill >= n) cuts = {0, n};
+    else if (fill >= 0.2 * n) cuts = {0, fill, n};
+    else {
+      std::vector<int> c2{0, fill};
+      for (size_t k = 2; k + 1 < cuts.size(); ++k) c2.push_back(std::max(cuts[k], fill + (int)(k - 2) + 1));
+      c2.push_back(n);
+      cuts = c2;
+    }
+  }
+  return cuts;
+}
+}  // extern "C++"
+
+int csdo_do_phase_cuts(const int32_t* agents_per_world, int32_t n_worlds, int32_t min_first_agents, int32_t* cuts /* [5] */) {
+  if (!agents_per_world || n_worlds < 1 || !cuts) return CSDO_EINVAL;
+  return guarded([&]() {
+    const std::vector<int> c = do_phase_cuts(std::vector<int>(agents_per_world, agents_per_world + n_worlds), min_first_agents);
+    for (size_t k = 0; k < 5; ++k) cuts[k] = k < c.size() ? c[k] : -1;
+    return (int)c.size() - 1;
+  });
+}
+
+int csdo_do_phase(csdo_handle h, const csdo_coarse_world* worlds, int32_t n_worlds, const csdo_vehicle* veh, const csdo_qp_parm* parm,
+                  csdo_result* results, int32_t* initial_inter_legal, csdo_do_phase_timing* timing) {
+  if (!h || h->multi || h->borrowed || h->run_pending || !worlds || n_worlds < 1 || !veh || !parm || !results) return CSDO_EINVAL;
+  return guarded([&]() -> int {
+    const double t0 = now_s();
+    csdo_do_phase_timing T{};
+    std::vector<int> agents((size_t)n_worlds), horizon((size_t)n_worlds);
+    bool one_class = true;   // horizons 129 .. 234 run in ONE kernel class (512 threads, everything in LDS): only such a job is streamed
+    for (int w = 0; w < n_worlds; ++w) {
+      const csdo_coarse_world& W = worlds[w];
+      if (!W.states || !W.actions || !W.path_off || !W.goals || W.Na < 1 || W.n_obs < 0 || (W.n_obs > 0 && !W.obstacles)) return CSDO_EINVAL;
+      agents[w] = W.Na;
+      horizon[w] = csdo_do_phase_horizon(W.path_off, W.Na, parm);
+      if (horizon[w] < 2) return CSDO_EINVAL;
+      one_class = one_class && horizon[w] > 128 && horizon[w] <= 234;
+    }
+    std::vector<int> cuts = one_class ? do_phase_cuts(agents, 230) : std::vector<int>{0, n_worlds};
+    // bridge of worlds [w0, w1) on the host threads, then the csdo_problem views of its outputs
+    struct Bridged {
+      std::vector<csdo_bridge_out> outs;
+      std::vector<csdo_problem> probs;
+      ~Bridged() {
+        for (auto& o : outs) bridge_free(&o);
+      }
+    };
+    auto bridge = [&](const int w0, const int w1, Bridged& B) -> int {
+      const int n = w1 - w0;
+      B.outs.assign((size_t)n, csdo_bridge_out{});
+      std::vector<const double*> st((size_t)n), go((size_t)n);
+      std::vector<const int32_t*> ac((size_t)n), po((size_t)n);
+      std::vector<int32_t> na((size_t)n);
+      for (int k = 0; k < n; ++k) {
+        const csdo_coarse_world& W = worlds[w0 + k];
+        st[k] = W.states; ac[k] = W.actions; po[k] = W.path_off; go[k] = W.goals; na[k] = W.Na;
+      }
+      const int rc = csdo_preprocess_batch(n, st.data(), ac.data(), po.data(), na.data(), go.data(), veh, parm, B.outs.data());
+      if (rc != CSDO_OK) {
+        B.outs.clear();   // (csdo_preprocess_batch has released what it had made)
+        return rc;
+      }
+      B.probs.assign((size_t)n, csdo_problem{});
+      for (int k = 0; k < n; ++k) {
+        const csdo_coarse_world& W = worlds[w0 + k];
+        const csdo_bridge_out& o = B.outs[(size_t)k];
+        if (o.Nt != horizon[w0 + k]) return CSDO_EINVAL;   // (the caller sized its result arrays by csdo_do_phase_horizon)
+        csdo_problem& P = B.probs[(size_t)k];
+        P.Na = o.Na; P.Nt = o.Nt; P.x0_bar = o.x0_bar; P.plane_off = o.plane_off; P.planes = o.planes;
+        P.dimx = W.dimx; P.dimy = W.dimy; P.n_obs = W.n_obs; P.obstacles = W.obstacles; P.veh = *veh; P.parm = *parm;
+        if (initial_inter_legal) initial_inter_legal[w0 + k] = o.initial_inter_legal;
+      }
+      return CSDO_OK;
+    };
+    auto one_launch = [&](Bridged& first, const int w_first_end) -> int {   // everything on this handle; `first` = worlds [0, w_first_end) bridged
+      Bridged rest;
+      int rc;
+      const double tb = now_s();
+      if (w_first_end < n_worlds && (rc = bridge(w_first_end, n_worlds, rest)) != CSDO_OK) return rc;
+      std::vector<csdo_problem> all(first.probs);
+      all.insert(all.end(), rest.probs.begin(), rest.probs.end());
+      const double tu = now_s();
+      const bool was = h->host_results;
+      h->host_results = true;
+      rc = upload_impl(h, all.data(), n_worlds);
+      h->host_results = was;
+      if (rc != CSDO_OK) return rc;
+      const double tr = now_s();
+      if ((rc = csdo_dsqp_run(h, nullptr)) != CSDO_OK) return rc;
+      T.kernels_done = now_s() - t0;
+      if ((rc = download_impl(h, results, n_worlds)) != CSDO_OK) return rc;
+      T.first_launch = tr - t0;
+      T.n_chunks = 1;
+      T.streamed = 0;
+      T.chunk_worlds[0] = n_worlds;
+      T.chunk_bridge[0] += tu - tb;
+      T.chunk_upload[0] = tr - tu;
+      T.chunk_kernel[0] = h->last_kernel_s;
+      return CSDO_OK;
+    };
+    int rc = CSDO_OK;
+    if (cuts.size() == 2) {
+      Bridged all;
+      const double tb = now_s();
+      if ((rc = bridge(0, n_worlds, all)) != CSDO_OK) return rc;
+      T.chunk_bridge[0] = now_s() - tb;
+      rc = one_launch(all, n_worlds);
+    } else {
+      const int n_chunks = (int)cuts.size() - 1;
+      std::vector<csdo_handle> flying;
+      // a chunk that fails (an obstacle-heavy world hits CSDO_ELIMIT at its upload) leaves the earlier ones running: collect them
+      auto drain = [&](int code) {
+        for (csdo_handle k : flying) (void)csdo_dsqp_wait(k);
+        return code;
+      };
+      int next_lane = 0;
+      bool done = false;
+      for (int c = 0; c < n_chunks && !done; ++c) {
+        if (!h->stream_kids[c] && (rc = csdo_dsqp_create_shared(&h->stream_kids[c], h, c)) != CSDO_OK) return drain(rc);
+        csdo_handle kid = h->stream_kids[c];
+        if (kid->run_pending) return drain(CSDO_EINVAL);
+        kid->host_results = true;   // the last chunk's D2H copy is the one nothing would hide
+        kid->min_mode = h->min_mode;
+        Bridged B;
+        const double tb = now_s();
+        if ((rc = bridge(cuts[c], cuts[c + 1], B)) != CSDO_OK) return drain(rc);
+        const double tu = now_s();
+        if ((rc = upload_impl(kid, B.probs.data(), cuts[c + 1] - cuts[c])) != CSDO_OK) return drain(rc);
+        const double tr = now_s();
+        const int ng = (int)kid->groups.size();
+        if (c == 0 && ng > 1) {
+          // several kernel classes after all (plane counts decide too): chunks of such launches in flight at once fragment the CUs
+          // (measured: map50 87 ms streamed against 59, room50 115 against 68) - one launch of everything, on this handle
+          T.chunk_bridge[0] = tu - tb;
+          rc = one_launch(B, cuts[1]);
+          done = true;
+          break;
+        }
+        if ((rc = csdo_dsqp_set_lane(kid, next_lane)) != CSDO_OK) return drain(rc);
+        next_lane = (next_lane + std::max(ng, 1)) % 4;
+        if ((rc = csdo_dsqp_run_async(kid, nullptr)) != CSDO_OK) return drain(rc);
+        flying.push_back(kid);
+        if (c == 0) T.first_launch = now_s() - t0;
+        T.chunk_worlds[c] = cuts[c + 1] - cuts[c];
+        T.chunk_bridge[c] = tu - tb;
+        T.chunk_upload[c] = tr - tu;
+      }
+      if (!done) {
+        T.n_chunks = n_chunks;
+        T.streamed = 1;
+        for (int c = 0; c < n_chunks; ++c) {
+          csdo_handle kid = flying[(size_t)c];
+          int rc_c = csdo_dsqp_wait(kid);
+          T.kernels_done = now_s() - t0;
+          T.chunk_kernel[c] = kid->last_kernel_s;
+          if (rc_c == CSDO_OK) rc_c = download_impl(kid, results + cuts[c], cuts[c + 1] - cuts[c]);
+          if (rc_c != CSDO_OK && rc == CSDO_OK) rc = rc_c;   // (the later chunks are still collected)
+        }
+      }
+    }
+    if (rc != CSDO_OK) return rc;
+    T.total = now_s() - t0;
+    for (int w = 0; w < n_worlds; ++w) results[w].t_total = T.total;
+    if (timing) *timing = T;
+    return CSDO_OK;
+  });
 }
 
 #if defined(CSDO_PROFILE_PHASES)

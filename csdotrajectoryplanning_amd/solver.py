@@ -92,7 +92,7 @@ class DsqpHandle:
         return lib().csdo_dsqp_last_kernel_seconds(self._h)
 
     def do_phase_stream(self, items, veh, parm, fractions=(0.08, 0.27, 0.65), out=None, order=None, single_launch_if_mixed=True,
-                        min_first_agents=230, host_results=True):
+                        min_first_agents=230, host_results=True, device_bridge=False):
         """The DO phase of csdo.cc:111-148 for a batch of worlds, streamed in chunks of worlds: the host bridge, the packing
         and the H2D copies of chunk k + 1 run under the solve of chunk k (csdo_dsqp_create_shared / csdo_dsqp_run_async), the
         results of a chunk come back under the solve of the later ones.  The chunks grow (a small first one starts the GPU
@@ -104,6 +104,8 @@ class DsqpHandle:
         worlds on this handle instead (which replaces the batch this handle held).
         min_first_agents: the first chunk is enlarged until it holds that many agents (0: the fractions as given).
         host_results: the chunks' kernels write their results into page-locked host memory (csdo_dsqp_set_host_results).
+        device_bridge: a job that is solved by one launch is bridged by csdo_preprocess_device_batch (pair search and planes on the
+        device; round 4's choice) instead of the host threads (round 6: 60 worlds in 1 - 3 ms on the library's pool).
         Returns (solutions in the order of `items`, dict of host-side timings in seconds)."""
         import time
         n = len(items)
@@ -123,7 +125,10 @@ class DsqpHandle:
         if mixed_by_horizon:
             # known before anything is bridged: the device bridge of all worlds in one call (csdo_preprocess_device_batch), one launch
             tb = time.perf_counter()
-            bridged = self.interpolate_and_planes_batch([items[i] for i in idx], veh, parm)
+            if device_bridge:
+                bridged = self.interpolate_and_planes_batch([items[i] for i in idx], veh, parm)
+            else:
+                bridged = interpolate_and_planes_batch_host([items[i] for i in idx], veh, parm)
             tu = time.perf_counter()
             self.set_host_results(host_results)
             try:
@@ -208,6 +213,43 @@ class DsqpHandle:
         timing["total"] = time.perf_counter() - t0
         timing["streamed"] = True
         return sols, timing
+
+    def do_phase(self, items, veh, parm, out=None):
+        """csdo_do_phase: the DO phase of csdo.cc:111-148 for a batch of worlds in ONE library call - bridge on the library's host
+        threads, streamed in chunks when the job is of one kernel class (else one launch), results written by the kernels into
+        page-locked host memory and scattered into the arrays returned here.  The C++ form of do_phase_stream (same chunks, same
+        bits), without an interpreter between its stages.
+        items: per world (states, actions, path_off, goals, dimx, dimy, obstacles); out: what a previous call returned first.
+        Returns (solutions in the order of `items`, dict of host-side timings in seconds, initial_inter_legal per world)."""
+        n = len(items)
+        keep = []
+        cw = (abi.CoarseWorld * n)()
+        for k, (st, ac, po, G, dimx, dimy, obs) in enumerate(items):
+            st = np.ascontiguousarray(st, dtype=np.float64)
+            ac = np.ascontiguousarray(ac, dtype=np.int32)
+            po = np.ascontiguousarray(po, dtype=np.int32)
+            G = np.ascontiguousarray(G, dtype=np.float64)
+            obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+            keep.append((st, ac, po, G, obs))
+            c = cw[k]
+            c.states, c.actions, c.path_off, c.goals = abi.as_double_p(st), abi.as_int32_p(ac), abi.as_int32_p(po), abi.as_double_p(G)
+            c.obstacles, c.Na, c.n_obs, c.dimx, c.dimy = abi.as_double_p(obs), len(po) - 1, obs.shape[0], float(dimx), float(dimy)
+        if out is None:
+            ni = int(parm.num_interpolation) + 1
+            out = [Solution.allocate(len(it[2]) - 1, ni * (int(np.max(np.diff(np.asarray(it[2])))) - 1) + 1) for it in items]
+        res = (abi.Result * n)(*[s_._c for s_ in out])
+        legal = np.zeros(n, np.int32)
+        tm = abi.DoPhaseTiming()
+        check(lib().csdo_do_phase(self._h, cw, n, C.byref(veh), C.byref(parm), res, abi.as_int32_p(legal), C.byref(tm)), "csdo_do_phase")
+        del keep
+        for s_, r in zip(out, res):
+            s_._c = r
+            s_.finish()
+        nc = int(tm.n_chunks)
+        timing = {"first_launch": tm.first_launch, "kernels_done": tm.kernels_done, "total": tm.total, "streamed": bool(tm.streamed),
+                  "chunks": [{"worlds": int(tm.chunk_worlds[c]), "bridge": tm.chunk_bridge[c], "upload": tm.chunk_upload[c],
+                              "kernel": tm.chunk_kernel[c]} for c in range(nc)]}
+        return out, timing, legal
 
     def transfer_seconds(self):
         """Host seconds of the last upload / download: dict(pack, stage, h2d, d2h, unpack)."""

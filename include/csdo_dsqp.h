@@ -286,6 +286,40 @@ int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const i
                           const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
                           const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs);
 
+/* The whole DO phase of a batch of worlds in one call - what csdo.cc:111-148 does for one world: InterpolateInitalGuess,
+ * findNeighborPairsByTrustRegion, calcEqualInterPlanes, SolverDSQP - coarse front-end paths in, trajectories out.
+ * A job whose worlds all run in the 512-thread kernel class (horizons 129 .. 234, known from the coarse paths) is STREAMED in three
+ * growing chunks of worlds on csdo_dsqp_create_shared handles that `h` keeps: chunk k + 1 is bridged on the library's host threads,
+ * packed and copied under chunk k's solve, every workgroup writes its agent's results into page-locked host memory when the agent
+ * is done (csdo_dsqp_set_host_results), each chunk is scattered into `results` under the later chunks' solves.  Any other job is
+ * bridged at once and solved by one launch on `h` (chunks of several launch groups in flight at once fragment the CUs).  Either way
+ * results[w] holds the bits csdo_preprocess + csdo_dsqp_solve return for world w alone.  The batch `h` held is replaced.
+ *   results[w]: caller-allocated as for csdo_dsqp_solve_batch, with Nt = csdo_do_phase_horizon(path_off, Na, parm) of world w;
+ *   initial_inter_legal [n_worlds] (may be null): findNeighborPairsByTrustRegion's return value per world;
+ *   timing (may be null): host seconds, per chunk and overall.
+ * One vehicle / parameter block for the whole batch.  Single-device handles only. */
+typedef struct csdo_coarse_world {
+  const double* states;        /* [path_off[Na]][3]: x, y, yaw of every path state, agent after agent */
+  const int32_t* actions;      /* [path_off[Na] - Na]: the move between consecutive states (0..5; csdo_front_end_plan's layout) */
+  const int32_t* path_off;     /* [Na + 1] */
+  const double* goals;         /* [Na][3] */
+  const double* obstacles;     /* [n_obs][3]: x, y, r */
+  int32_t Na, n_obs;
+  double dimx, dimy;
+} csdo_coarse_world;
+typedef struct csdo_do_phase_timing {
+  double first_launch, kernels_done, total;   /* seconds since the call began */
+  int32_t n_chunks, streamed;                 /* streamed = 0: one launch (chunk 0 = everything) */
+  int32_t chunk_worlds[4];
+  double chunk_bridge[4], chunk_upload[4], chunk_kernel[4];
+} csdo_do_phase_timing;
+int32_t csdo_do_phase_horizon(const int32_t* path_off, int32_t Na, const csdo_qp_parm* parm);   /* Nt of the world's fixed-length guess (sqp/inter_agent_cons.cc:320-325), or a negative error code */
+int csdo_do_phase(csdo_handle h, const csdo_coarse_world* worlds, int32_t n_worlds, const csdo_vehicle* veh, const csdo_qp_parm* parm,
+                  csdo_result* results /* [n_worlds] */, int32_t* initial_inter_legal, csdo_do_phase_timing* timing);
+/* The chunk boundaries csdo_do_phase would use for worlds of these sizes if they are all streamable: cuts[0 .. n] = 0, c1, ..., n_worlds
+ * (unused entries -1); returns the number of chunks (host code). */
+int csdo_do_phase_cuts(const int32_t* agents_per_world, int32_t n_worlds, int32_t min_first_agents, int32_t* cuts /* [5] */);
+
 /* Front end (host): priority-based search, each agent planned by a spatiotemporal hybrid A* that yields to the agents
  * ranked above it.  starts / goals [Na][3] = x, y, yaw.  On success (status 1) the paths come back in exactly the layout
  * csdo_preprocess takes: states [sum L_a][3], actions [sum (L_a - 1)] (0..5 = the six arc primitives of

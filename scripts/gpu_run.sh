@@ -12,6 +12,7 @@
 #     round                                 the round's record: all bench lines, phase profiles, sweep, ... (then scripts/collect_round.sh)
 #     boxes                                 safe-box ablation builds
 #     profile:<workload>                    rocprofv3 kernel trace + PMC passes (scripts/profile_round.sh), summaries into profiles/ by collect
+#     summarize                             ... and on the box (put it between the profile steps and `round`)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 TAG=$1; shift
@@ -56,6 +57,12 @@ PY
       CSDO_DIAG_LIB=${lib:-csdotrajectoryplanning_amd/libcsdo_hip_prof.so} timeout 900 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 $w > $O/phases_${w}_$tagl.txt 2>&1; head -12 $O/phases_${w}_$tagl.txt ;;
     profile)
       bash scripts/profile_round.sh $TAG $arg ;;
+    summarize)  # the counter summaries of this call's profile:<workload> steps into profiles/ ON THE BOX, so that bench lines run later in
+                # the same call (round) quote counters taken from the very library they time (bench.py: _newest_pmc compares the hashes)
+      for w in map100 map50 synth1024 room50 agents100; do
+        [ -d gpurun_out/${TAG}_$w ] && python scripts/summarize_profiles.py gpurun_out $TAG $w > /dev/null 2>&1
+      done
+      grep -h kernel_source_hash profiles/${TAG}_*pmc_summary.json | sort | uniq -c ;;
     refined)   # what csdo_qp_parm::solve_refinement costs: the same bench lines with the flag on
       for w in ${arg//,/ }; do
         for m in 1 2; do

@@ -1548,7 +1548,69 @@ int csdo_do_phase_cuts(const int32_t* agents_per_world, int32_t n_worlds, int32_
 
 int csdo_do_phase(csdo_handle h, const csdo_coarse_world* worlds, int32_t n_worlds, const csdo_vehicle* veh, const csdo_qp_parm* parm,
                   csdo_result* results, int32_t* initial_inter_legal, csdo_do_phase_timing* timing) {
-  if (!h || h->multi || h->borrowed || h->run_pending || !worlds || n_worlds < 1 || !veh || !parm || !results) return CSDO_EINVAL;
+  if (!h || h->borrowed || h->run_pending || !worlds || n_worlds < 1 || !veh || !parm || !results) return CSDO_EINVAL;
+  if (h->multi) {
+    // Several GPUs: the WORLDS are dealt out - contiguous runs of equal weight (agents x horizon), one per device -, every device runs
+    // its own DO phase on its own host thread, results land in the caller's arrays directly.  No collective: worlds are independent.
+    return guarded([&]() -> int {
+      const double t0 = now_s();
+      const std::vector<csdo_handle>& kids = h->multi->kids;
+      const int K = (int)kids.size();
+      std::vector<double> weight((size_t)n_worlds);
+      double total = 0.0;
+      for (int w = 0; w < n_worlds; ++w) {
+        if (!worlds[w].path_off || worlds[w].Na < 1) return CSDO_EINVAL;
+        const int nt = csdo_do_phase_horizon(worlds[w].path_off, worlds[w].Na, parm);
+        if (nt < 2) return CSDO_EINVAL;
+        weight[w] = (double)worlds[w].Na * nt;
+        total += weight[w];
+      }
+      std::vector<int> cut((size_t)K + 1, n_worlds);
+      cut[0] = 0;
+      double run = 0.0;
+      for (int w = 0, k = 1; w < n_worlds && k < K; ++w) {
+        run += weight[w];
+        while (k < K && run >= total * k / K) cut[k++] = w + 1;
+      }
+      std::vector<int> rcs((size_t)K, CSDO_OK);
+      std::vector<csdo_do_phase_timing> tms((size_t)K);
+      {
+        struct Joiner {
+          std::vector<std::thread> t;
+          ~Joiner() {
+            for (auto& x : t)
+              if (x.joinable()) x.join();
+          }
+        } pool;
+        auto part = [&](const int k) {
+          const int n_k = cut[k + 1] - cut[k];
+          if (n_k > 0)
+            rcs[k] = csdo_do_phase(kids[k], worlds + cut[k], n_k, veh, parm, results + cut[k],
+                                   initial_inter_legal ? initial_inter_legal + cut[k] : nullptr, &tms[k]);
+        };
+        for (int k = 1; k < K; ++k) {
+          try {
+            pool.t.emplace_back(part, k);
+          } catch (...) {
+            part(k);
+          }
+        }
+        const DeviceGuard keep_callers_device;
+        part(0);
+      }
+      for (int k = 0; k < K; ++k)
+        if (rcs[k] != CSDO_OK) return rcs[k];
+      csdo_do_phase_timing T = tms[0];   // the first device's chunks; the batch is done when the last device is
+      for (int k = 1; k < K; ++k) {
+        T.kernels_done = std::max(T.kernels_done, tms[k].kernels_done);
+        T.first_launch = std::max(T.first_launch, tms[k].first_launch);
+      }
+      T.total = now_s() - t0;
+      for (int w = 0; w < n_worlds; ++w) results[w].t_total = T.total;
+      if (timing) *timing = T;
+      return CSDO_OK;
+    });
+  }
   return guarded([&]() -> int {
     const double t0 = now_s();
     csdo_do_phase_timing T{};

@@ -297,7 +297,9 @@ int csdo_preprocess_batch(int32_t n_worlds, const double* const* states, const i
  *   results[w]: caller-allocated as for csdo_dsqp_solve_batch, with Nt = csdo_do_phase_horizon(path_off, Na, parm) of world w;
  *   initial_inter_legal [n_worlds] (may be null): findNeighborPairsByTrustRegion's return value per world;
  *   timing (may be null): host seconds, per chunk and overall.
- * One vehicle / parameter block for the whole batch.  Single-device handles only. */
+ * One vehicle / parameter block for the whole batch.  On a csdo_dsqp_create_multi handle the WORLDS are dealt out - contiguous runs of
+ * equal weight (agents x horizon), one per device - and every device runs its own DO phase on a host thread of its own (no collective:
+ * worlds are independent); `timing` then describes the first device's chunks and the batch's overall times. */
 typedef struct csdo_coarse_world {
   const double* states;        /* [path_off[Na]][3]: x, y, yaw of every path state, agent after agent */
   const int32_t* actions;      /* [path_off[Na] - Na]: the move between consecutive states (0..5; csdo_front_end_plan's layout) */

@@ -14,6 +14,8 @@ done
 [ -f gpurun_out/$TAG/stream_map100.txt ] && grep -v amdgpu gpurun_out/$TAG/stream_map100.txt > profiles/${TAG}_stream_map100.txt
 [ -f gpurun_out/$TAG/single_instance_times.txt ] && grep -v amdgpu gpurun_out/$TAG/single_instance_times.txt > profiles/${TAG}_single_instance_times.txt
 [ -f gpurun_out/$TAG/host_info.txt ] && cp gpurun_out/$TAG/host_info.txt profiles/${TAG}_host_info.txt
+[ -f gpurun_out/$TAG/do_phase_times.txt ] && grep -v amdgpu gpurun_out/$TAG/do_phase_times.txt > profiles/${TAG}_do_phase_times.txt
+[ -f gpurun_out/$TAG/host_stage_times.txt ] && grep -v amdgpu gpurun_out/$TAG/host_stage_times.txt > profiles/${TAG}_host_stage_times.txt
 # (a phase profile is a table, not an error message: a stale libcsdo_hip_prof.so - `make -C csdotrajectoryplanning_amd/csrc prof` after every
 #  change of the sources - leaves a load error in the file, which is not copied)
 for pair in phases_map100:phase_profile_map100 phases_map50:phase_profile_map50 phases_room50_long:phase_profile_room50_long_horizons; do

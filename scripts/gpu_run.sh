@@ -85,7 +85,10 @@ PY
       timeout 600 python scripts/stream_fractions.py map100 "0.08,0.27,0.65" > $O/stream_map100.txt 2>&1
       timeout 900 python scripts/authors_sweep.py $O/authors_sweep.json > $O/authors_sweep.log 2>&1
       timeout 300 python scripts/single_instance_times.py > $O/single_instance_times.txt 2>&1
-      timeout 300 python scripts/group_times.py room50 > $O/group_times_room50.txt 2>&1 ;;
+      timeout 300 python scripts/group_times.py room50 > $O/group_times_room50.txt 2>&1
+      timeout 600 python scripts/do_phase_times.py > $O/do_phase_times.txt 2>&1          # csdo_do_phase against the Python-driven pipeline, all workloads
+      timeout 300 python scripts/host_stage_times.py map100 60 > $O/host_stage_times.txt 2>&1
+      CSDO_HOST_THREADS=1 timeout 300 python scripts/host_stage_times.py map100 60 >> $O/host_stage_times.txt 2>&1 ;;
     boxes)     # what the pieces of a safe box cost: phase-timer builds that do one piece twice (scripts/build_prof_ablation.sh)
       for t in "" _box2x_ALL _box2x_PASSES _box2x_REPLAY _box2x_CULL; do
         CSDO_PROF_LIB=libcsdo_hip_prof$t.so timeout 600 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 map100 > $O/phases$t.txt 2>&1

@@ -102,3 +102,28 @@ def test_do_phase_over_several_devices_deals_out_worlds(gpu_handle):
             assert _same(got1[0], ref[0])
         finally:
             hm.close()
+
+
+def _c_consumer():
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    mk = subprocess.run(["make", "-C", here, "do_phase_main"], capture_output=True, text=True)
+    assert mk.returncode == 0 and "warning" not in (mk.stdout + mk.stderr).lower(), mk.stdout + mk.stderr
+    return subprocess.run([os.path.join(here, "do_phase_main")], capture_output=True, text=True, timeout=300)
+
+
+def test_a_plain_c_program_binds_the_header_and_fails_loudly_without_a_device():
+    """tests/cpp/do_phase_main.c (gcc -std=c99 -pedantic, no warning): the front end runs on the host; without a HIP device
+    csdo_dsqp_create returns CSDO_ENODEV - there is no CPU fallback behind the ABI."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the GPU test runs the same program to the end")
+    run = _c_consumer()
+    assert run.returncode == 3 and "front end ok" in run.stdout and "no device: error -2" in run.stdout, (run.stdout, run.stderr)
+
+
+@pytest.mark.gpu
+def test_a_plain_c_program_runs_front_end_and_do_phase():
+    run = _c_consumer()
+    assert run.returncode == 0 and "copies identical 1" in run.stdout, (run.stdout, run.stderr)

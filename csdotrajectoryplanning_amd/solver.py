@@ -220,7 +220,10 @@ class DsqpHandle:
         page-locked host memory and scattered into the arrays returned here.  The C++ form of do_phase_stream (same chunks, same
         bits), without an interpreter between its stages.
         items: per world (states, actions, path_off, goals, dimx, dimy, obstacles); out: what a previous call returned first.
-        Returns (solutions in the order of `items`, dict of host-side timings in seconds, initial_inter_legal per world)."""
+        Returns (solutions in the order of `items`, dict of host-side timings in seconds, initial_inter_legal per world);
+        timing["total"] is the library call's own clock, timing["total_with_binding"] includes this method's marshalling."""
+        import time
+        t_py0 = time.perf_counter()
         n = len(items)
         keep = []
         cw = (abi.CoarseWorld * n)()
@@ -249,6 +252,7 @@ class DsqpHandle:
         timing = {"first_launch": tm.first_launch, "kernels_done": tm.kernels_done, "total": tm.total, "streamed": bool(tm.streamed),
                   "chunks": [{"worlds": int(tm.chunk_worlds[c]), "bridge": tm.chunk_bridge[c], "upload": tm.chunk_upload[c],
                               "kernel": tm.chunk_kernel[c]} for c in range(nc)]}
+        timing["total_with_binding"] = time.perf_counter() - t_py0      # ... with this method's marshalling around the library call
         return out, timing, legal
 
     def transfer_seconds(self):

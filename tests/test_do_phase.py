@@ -127,3 +127,37 @@ def test_a_plain_c_program_binds_the_header_and_fails_loudly_without_a_device():
 def test_a_plain_c_program_runs_front_end_and_do_phase():
     run = _c_consumer()
     assert run.returncode == 0 and "copies identical 1" in run.stdout, (run.stdout, run.stderr)
+
+
+@pytest.mark.gpu
+def test_two_handles_run_their_do_phases_at_once(gpu_handle):
+    """Two handles, two host threads, one csdo_do_phase each at the same time (they share the library's host threads and the GPU):
+    each gets the bits it gets alone."""
+    import threading
+    from csdotrajectoryplanning_amd import workloads
+    from csdotrajectoryplanning_amd.solver import DsqpHandle
+    jobs = {"a": ("map100", 6), "b": ("map50", 6)}
+    items, refs, veh, parm = {}, {}, None, None
+    for key, (name, n) in jobs.items():
+        built = [workloads.build_job(j) for j in workloads.workload_jobs(name, n)]
+        items[key] = [(*info["paths"], w.dimx, w.dimy, w.obstacles) for w, info in built]
+        refs[key] = gpu_handle.solve_batch([w for w, _ in built])
+        veh, parm = built[0][0].veh, built[0][0].parm
+    other = DsqpHandle(0)
+    try:
+        for _ in range(3):
+            got, err = {}, []
+
+            def run(key, handle):
+                try:
+                    got[key] = handle.do_phase(items[key], veh, parm)[0]
+                except Exception as e:   # noqa: BLE001
+                    err.append(e)
+            ta = threading.Thread(target=run, args=("a", gpu_handle))
+            tb = threading.Thread(target=run, args=("b", other))
+            ta.start(); tb.start(); ta.join(); tb.join()
+            assert not err, err
+            for key in jobs:
+                assert all(_same(g, r) for g, r in zip(got[key], refs[key])), key
+    finally:
+        other.close()

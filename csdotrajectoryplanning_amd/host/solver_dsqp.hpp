@@ -166,4 +166,117 @@ class SolverDSQP {
   bool initial_static_legal = true;
 };
 
+// The whole DO phase of csdo.cc:111-159 on the reference's own containers: InterpolateInitalGuess, findNeighborPairsByTrustRegion,
+// calcEqualInterPlanes and the SolverDSQP constructor in ONE library call (csdo_do_phase; include/csdo_dsqp.h).  Same getters and
+// public members as SolverDSQP, plus the bridge's verdict on the initial guess.
+//   PathT: `states` = sequence of pair<State, cost> with State fields x, y, yaw; `actions` = sequence of pair<Action, cost>, Action
+//          convertible to int (libMultiRobotPlanning::PlanResult<State, Action, double>, hybrid_a_star/planresult.h:30-44);
+//   GoalRange: sequence of states with x, y, yaw (Instance::goal_states); the rest as for SolverDSQP.
+// What it does not hand back is x0_bar (csdo.cc dumps it with --initial_guess and with the corridors): csdo_preprocess gives that.
+class DoPhase {
+ public:
+  template <class OptRes, class PathT, class GoalRange, class ObstacleRange, class Parm>
+  DoPhase(std::vector<std::vector<OptRes>>& solutions, const std::vector<PathT>& coarse_paths, const GoalRange& goals, double dimx,
+          double dimy, const ObstacleRange& obstacles, const Parm& param, int logger_level = 2, int device = 0,
+          const csdo_vehicle* vehicle = nullptr, int solve_refinement = 0) {
+    const int Na = (int)coarse_paths.size();
+    std::vector<double> states, goal_xyz, obs;
+    std::vector<int32_t> actions, path_off{0};
+    for (const PathT& p : coarse_paths) {
+      for (const auto& s : p.states) {
+        states.push_back(s.first.x);
+        states.push_back(s.first.y);
+        states.push_back(s.first.yaw);
+      }
+      for (const auto& a : p.actions) actions.push_back((int32_t)a.first);
+      path_off.push_back((int32_t)(states.size() / 3));
+    }
+    for (const auto& g : goals) {
+      goal_xyz.push_back(g.x);
+      goal_xyz.push_back(g.y);
+      goal_xyz.push_back(g.yaw);
+    }
+    for (const auto& o : obstacles) {
+      obs.push_back(o.x);
+      obs.push_back(o.y);
+      obs.push_back(o.r);
+    }
+    if ((int)goal_xyz.size() != 3 * Na || Na < 1) throw std::runtime_error("csdo::DoPhase: one goal per path expected");
+    csdo_vehicle veh;
+    if (vehicle) veh = *vehicle; else csdo_vehicle_default(&veh);
+    csdo_qp_parm parm;
+    csdo_qp_parm_default(&veh, &parm);
+    parm.r_trust = param.r_trust;
+    parm.max_omega = param.max_omega;
+    parm.max_v = param.max_v;
+    parm.max_iter = (double)param.max_iter;
+    parm.delta_solution_threshold = param.delta_solution_threshold;
+    parm.max_violation = param.max_violation;
+    parm.osqp_max_iter = param.osqp_max_iter;
+    parm.num_interpolation = param.num_interpolation;
+    parm.dt = param.dt;
+    parm.fixed_corridor = param.fixed_corridor ? 1 : 0;
+    parm.solve_refinement = solve_refinement;
+    csdo_coarse_world W{};
+    W.states = states.data();
+    W.actions = actions.data();
+    W.path_off = path_off.data();
+    W.goals = goal_xyz.data();
+    W.obstacles = obs.data();
+    W.Na = Na;
+    W.n_obs = (int32_t)(obs.size() / 3);
+    W.dimx = dimx;
+    W.dimy = dimy;
+    const int Nt = csdo_do_phase_horizon(path_off.data(), Na, &parm);
+    if (Nt < 2) throw std::runtime_error("csdo::DoPhase: paths of fewer than two states");
+    std::vector<double> sol((size_t)Na * Nt * 6), cor((size_t)Na * Nt * 8);
+    std::vector<int32_t> admm(Na), last(Na);
+    num_iterations.assign(Na, 0);
+    csdo_result R{};
+    R.solutions = sol.data();
+    R.corridors = cor.data();
+    R.sqp_iters = num_iterations.data();
+    R.admm_iters = admm.data();
+    R.last_status = last.data();
+    int32_t inter_legal = 1;
+    csdo_handle h = nullptr;
+    int rc = csdo_dsqp_create(&h, device);
+    if (rc == CSDO_OK) rc = csdo_do_phase(h, &W, 1, &veh, &parm, &R, &inter_legal, nullptr);
+    if (h) csdo_dsqp_destroy(h);
+    if (rc != CSDO_OK) throw std::runtime_error("csdo_do_phase failed with code " + std::to_string(rc));
+    solutions.assign(Na, std::vector<OptRes>(Nt));
+    corridors.assign(Na, std::vector<Corridor>(Nt));
+    for (int a = 0; a < Na; ++a)
+      for (int t = 0; t < Nt; ++t) {
+        const double* s = &sol[((size_t)a * Nt + t) * 6];
+        OptRes& r = solutions[a][t];
+        r.x = s[0]; r.y = s[1]; r.yaw = s[2]; r.steer = s[3]; r.v = s[4]; r.d_steer = s[5];
+        const double* c = &cor[((size_t)a * Nt + t) * 8];
+        corridors[a][t] = Corridor{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};
+      }
+    admm_iterations.assign(admm.begin(), admm.end());
+    if (logger_level >= 2)
+      std::printf("csdo::DoPhase: %d agents, Nt = %d, kernels %.3f ms, call %.3f ms, solver status %d, initial guess legal %d / %d\n", Na, Nt,
+                  R.t_device * 1e3, R.t_total * 1e3, (int)R.solver_status, (int)inter_legal, (int)R.initial_static_legal);
+    solve_status = R.solver_status;
+    initial_static_legal = R.initial_static_legal != 0;
+    initial_inter_legal = inter_legal != 0;
+    max_individual_opt_runtime = R.t_max_individual;
+  }
+
+  int getSolverStatus() const { return solve_status; }
+  double getMaxOfRuntimes() const { return max_individual_opt_runtime; }
+  bool get_initial_static_legal() const { return initial_static_legal; }
+  bool get_initial_inter_legal() const { return initial_inter_legal; }   // findNeighborPairsByTrustRegion's return value (csdo.cc:120-126)
+
+  std::vector<int> num_iterations;
+  std::vector<std::vector<Corridor>> corridors;
+  std::vector<int> admm_iterations;
+
+ private:
+  int solve_status = 0;
+  double max_individual_opt_runtime = -1;
+  bool initial_static_legal = true, initial_inter_legal = true;
+};
+
 }  // namespace csdo

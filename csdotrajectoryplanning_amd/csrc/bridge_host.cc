@@ -19,7 +19,23 @@ namespace {
 // One world's bridge is cut into pieces - agents, blocks of timesteps, blocks of pairs - for up to this many of the library's host
 // threads: a single 50-vehicle instance is 1.3 ms of bridge on one thread, a streamed DO phase's first chunk is five worlds on a
 // machine with a few dozen cores.  The pieces write disjoint outputs; the pair list is concatenated in (t, i, j) order.
-constexpr int HOST_THREADS_PER_WORLD = 16;
+constexpr int HOST_THREADS_PER_WORLD_MAX = 16;
+// ... but no more than the pool's threads divided by the worlds being bridged right now (a batch of sixty worlds on sixty-four threads
+// is one thread per world: cutting those worlds into pieces as well only made the threads queue up at the pool - 60 worlds of the
+// map50 set 1.7 ms against 8 ms of serial work / 64).  The stages of a world's bridge read the share through a thread-local.
+std::atomic<int> worlds_in_flight{0};
+thread_local int HOST_THREADS_PER_WORLD = HOST_THREADS_PER_WORLD_MAX;
+struct WorldInFlight {
+  int before;
+  WorldInFlight() : before(HOST_THREADS_PER_WORLD) {
+    const int n = worlds_in_flight.fetch_add(1) + 1;
+    HOST_THREADS_PER_WORLD = std::max(1, std::min(HOST_THREADS_PER_WORLD_MAX, (HostPool::get().helpers() + 1) / n));
+  }
+  ~WorldInFlight() {
+    worlds_in_flight.fetch_sub(1);
+    HOST_THREADS_PER_WORLD = before;
+  }
+};
 
 struct Veh {
   float r, LF, LB, W, f2x, r2x, rv;
@@ -346,6 +362,7 @@ int bridge_planes(const BridgeCentres& C, const int32_t* pairs, size_t n_pairs_i
 
 int bridge_preprocess(const double* states, const int32_t* actions, const int32_t* path_off, int32_t Na,
                       const double* goals, const csdo_vehicle* vehp, const csdo_qp_parm* parm, csdo_bridge_out* out) {
+  const WorldInFlight share_of_the_pool;
   BridgeCentres C;
   int rc = bridge_interpolate(states, actions, path_off, Na, goals, vehp, parm, out, C);
   if (rc != CSDO_OK) return rc;

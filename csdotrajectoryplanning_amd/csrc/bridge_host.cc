@@ -140,6 +140,11 @@ int bridge_interpolate(const double* states, const int32_t* actions, const int32
       cur[1] = goals[3 * a + 1];
       cur[2] = goals[3 * a + 2];
     }
+    const size_t cap = (size_t)(L - 1) * (size_t)(n + 1) + 1;   // n + 1 poses per move: one allocation per array instead of a dozen
+    X[a].reserve(cap);
+    Y[a].reserve(cap);
+    YAW[a].reserve(cap);
+    ACT[a].reserve(cap);
     X[a].push_back(cur[0]);
     Y[a].push_back(cur[1]);
     YAW[a].push_back(cur[2]);

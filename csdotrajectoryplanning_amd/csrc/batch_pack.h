@@ -41,6 +41,12 @@ inline int fac_stride(int Nt) { return (Nt + 1) & ~1; }
 struct PackSizes { size_t agents, worlds, x0, planes, tstart, obstacles; };
 struct PackPlace { double* x0; PlaneDev* planes; int32_t* tstart; double* obstacles; };
 using PackPlacer = std::function<int(const PackSizes&, PackPlace&)>;
+// a placer that places nothing: descriptors, offsets and the work estimates only (csdo_dsqp_estimate_work, the sharding pass of a
+// multi-device upload) - the big arrays are neither allocated nor filled
+inline int pack_nothing(const PackSizes&, PackPlace& at) {
+  at = PackPlace{nullptr, nullptr, nullptr, nullptr};
+  return CSDO_OK;
+}
 
 inline SolverParams make_params(const csdo_vehicle& v, const csdo_qp_parm& p) {
   SolverParams s{};
@@ -153,10 +159,11 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb, 
         wd.obs_off = (int32_t)(o.obs / 3);
         wd.n_obs = W.n_obs;
         hb.worlds[w] = wd;
-        if (W.n_obs) std::memcpy(at.obstacles + o.obs, W.obstacles, sizeof(double) * 3 * (size_t)W.n_obs);
+        if (W.n_obs && at.obstacles) std::memcpy(at.obstacles + o.obs, W.obstacles, sizeof(double) * 3 * (size_t)W.n_obs);
       }
-      std::memcpy(at.x0 + o.x0 + (size_t)a_lo * W.Nt * 6, W.x0_bar + (size_t)a_lo * W.Nt * 6,
-                  sizeof(double) * (size_t)(a_hi - a_lo) * W.Nt * 6);
+      if (at.x0)
+        std::memcpy(at.x0 + o.x0 + (size_t)a_lo * W.Nt * 6, W.x0_bar + (size_t)a_lo * W.Nt * 6,
+                    sizeof(double) * (size_t)(a_hi - a_lo) * W.Nt * 6);
       const int64_t fac_per_agent = (int64_t)(FAC_E_DOUBLES + FAC_X_DOUBLES + COLD_DOUBLES) * fac_stride(W.Nt);
       std::vector<int> order, near_obs;
       std::vector<int32_t> ts((size_t)W.Nt + 1);
@@ -176,7 +183,7 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb, 
         std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return W.planes[p].t < W.planes[q].t; });
         ad.tstart_off = (int64_t)(o.tstart + (size_t)a * (W.Nt + 1));
         std::fill(ts.begin(), ts.end(), 0);
-        PlaneDev* dst = at.planes + ad.plane_off;
+        PlaneDev* dst = at.planes ? at.planes + ad.plane_off : nullptr;
         // Launch order.  A few per cent of the agents take 3-6x the median time (QPs that run to the iteration cap for
         // most SQP iterations) and decide the makespan of a batch unless they start early.  Measured on the two benchmark
         // sets with this repository's front-end paths (scripts/agent_times.py, 4500 agents): what marks them is a tight
@@ -194,7 +201,7 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb, 
           PlaneDev pd{};
           pd.t = pl.t;
           std::memcpy(pd.c, pl.c, sizeof(pd.c));
-          dst[k] = pd;
+          if (dst) dst[k] = pd;
           ts[pl.t + 1]++;
           const double* xs = W.x0_bar + ((size_t)a * W.Nt + pl.t) * 6;
           const double cy = std::cos(xs[2]), sy = std::sin(xs[2]);
@@ -239,7 +246,7 @@ inline int pack_worlds(const csdo_problem* worlds, int n_worlds, HostBatch& hb, 
           n_near += near;
         }
         for (int t = 0; t < W.Nt; ++t) ts[t + 1] += ts[t];
-        std::memcpy(at.tstart + ad.tstart_off, ts.data(), sizeof(int32_t) * ts.size());
+        if (at.tstart) std::memcpy(at.tstart + ad.tstart_off, ts.data(), sizeof(int32_t) * ts.size());
         const double tight = (n_near + 0.2 * n_violated) / (double)W.Nt;
         hb.launch_rank[o.agent + a] = (float)tight;
         hb.est_work[o.agent + a] = (float)((1.0 + 10.0 * std::min(tight, 1.0)) * (2.0 * W.Nt + ad.n_planes));

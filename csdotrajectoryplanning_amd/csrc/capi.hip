@@ -367,7 +367,8 @@ static int multi_upload(csdo_handle h, const csdo_problem* worlds, int32_t n_wor
   h->limit_bytes = 0;
   const double t0 = now_s();
   HostBatch all;   // validates the batch and yields the per-agent work estimate (csdo_dsqp_estimate_work's)
-  int rc = pack_worlds(worlds, n_worlds, all);
+  const PackPlacer estimates_only = pack_nothing;
+  int rc = pack_worlds(worlds, n_worlds, all, &estimates_only);
   if (rc == CSDO_ELIMIT) note_horizon_limit(h, worlds, n_worlds);
   if (rc != CSDO_OK) return rc;
   const int nk = (int)M.kids.size(), Na = (int)all.agents.size();
@@ -717,7 +718,8 @@ int csdo_dsqp_estimate_work(const csdo_problem* worlds, int32_t n_worlds, double
   if (!worlds || n_worlds < 1 || !est) return CSDO_EINVAL;
   try {
     HostBatch hb;
-    const int rc = pack_worlds(worlds, n_worlds, hb);
+    const PackPlacer estimates_only = pack_nothing;
+    const int rc = pack_worlds(worlds, n_worlds, hb, &estimates_only);
     if (rc != CSDO_OK) return rc;
     for (size_t a = 0; a < hb.est_work.size(); ++a) est[a] = (double)hb.est_work[a];
     return CSDO_OK;

@@ -11,6 +11,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -104,6 +105,18 @@ class HostPool {
     } catch (...) {   // std::system_error (the caller's cgroup may cap threads): the pool is what could be started
     }
     for (auto& t : thr_) t.detach();
+    // fork(): only the forking thread exists in the child.  The pool's lock is taken around the fork, so that the child does not inherit
+    // it locked by a thread that is not there, and the child starts with an empty pool (every loop runs on its caller).
+    pthread_atfork([]() { get().m_.lock(); }, []() { get().m_.unlock(); },
+                   []() {
+                     HostPool& p = get();
+                     p.q_.clear();
+                     p.idle_.clear();
+                     p.thr_.clear();
+                     p.queued_.store(0);
+                     p.spinning_.store(0);
+                     p.m_.unlock();
+                   });
   }
   // A thread that has just worked stays awake for a moment: the stages of a DO phase follow each other within microseconds (a world's
   // bridge is four loops in a row), and waking a sleeping thread costs more than such a loop's share of the work.

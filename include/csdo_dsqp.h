@@ -279,6 +279,9 @@ int csdo_preprocess_device(csdo_handle h, const double* states, const int32_t* a
 int csdo_preprocess_device_batch(csdo_handle h, int32_t n_worlds, const double* const* states, const int32_t* const* actions,
                                  const int32_t* const* path_off, const int32_t* Na, const double* const* goals,
                                  const csdo_vehicle* veh, const csdo_qp_parm* parm, csdo_bridge_out* outs /* [n_worlds] */);
+/* The library's host threads: ONE persistent pool (started at the first call that has something to share; at most 63 threads + the
+ * caller) serves the bridge, the packing of an upload and the scatter of a download, each cut into blocks.  The environment variable
+ * CSDO_HOST_THREADS caps it (1: every loop runs on its caller).  A forked child starts with an empty pool. */
 /* csdo_preprocess for a batch of worlds on a pool of host threads, no device work (it runs beside a solve that occupies every
  * CU: the streamed DO phase prepares its next chunk of worlds with it).  outs[w] as csdo_preprocess fills it; on error every
  * outs[w] is released and zeroed. */

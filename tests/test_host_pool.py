@@ -33,7 +33,17 @@ def digest():
 
 if __name__ == "__main__":
     first = digest()
-    if len(sys.argv) > 1 and sys.argv[1] == "fork":
+    if len(sys.argv) > 1 and sys.argv[1] in ("fork", "fork_busy"):
+        if sys.argv[1] == "fork_busy":              # another thread keeps the pool busy while this one forks (ctypes releases the GIL)
+            import threading
+            stop = []
+            def churn():
+                while not stop:
+                    digest()
+            bg = threading.Thread(target=churn, daemon=True)
+            bg.start()
+            import time
+            time.sleep(0.05)
         r, w = os.pipe()
         pid = os.fork()
         if pid == 0:
@@ -42,6 +52,9 @@ if __name__ == "__main__":
         os.waitpid(pid, 0)
         child = os.read(r, 100).decode()
         assert child == first, (child, first)
+        if sys.argv[1] == "fork_busy":
+            stop.append(1)
+            bg.join()
     print(first)
 """ % ROOT
 
@@ -65,6 +78,12 @@ def test_outputs_do_not_depend_on_the_number_of_host_threads():
 
 def test_a_forked_child_runs_its_loops_alone():
     assert len(_run(None, "fork")) == 64
+
+
+def test_a_fork_while_the_pool_is_busy_does_not_leave_the_child_with_a_locked_pool():
+    """pthread_atfork: the pool's lock is held around fork(), the child gets it unlocked and an empty pool (ten forks in a row)."""
+    for _ in range(10):
+        assert len(_run(None, "fork_busy")) == 64
 
 
 def test_many_caller_threads_at_once():

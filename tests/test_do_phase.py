@@ -109,7 +109,8 @@ def _c_consumer():
     import subprocess
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
     mk = subprocess.run(["make", "-C", here, "do_phase_main"], capture_output=True, text=True)
-    assert mk.returncode == 0 and "warning" not in (mk.stdout + mk.stderr).lower(), mk.stdout + mk.stderr
+    import re
+    assert mk.returncode == 0 and not re.search(r"\.[ch]:\d+:\d+: warning", mk.stdout + mk.stderr), mk.stdout + mk.stderr   # (the compiler's, not make's clock-skew notes)
     return subprocess.run([os.path.join(here, "do_phase_main")], capture_output=True, text=True, timeout=300)
 
 

@@ -36,9 +36,10 @@ Rank 0 prints ONE JSON line.
 
 metric  = agent-QP-iterations/sec: ADMM iterations executed by all agents of all ranks / wall time of the K steps (max
           over ranks): kernels only, inputs resident in HBM.  `value_e2e` is the same count over the PCIe-inclusive DO phase
-          of csdo.cc:111-148 (`do_phase_e2e`: bridge with its pair search on the device + pack + H2D + kernels + D2H +
-          scatter, host wall clock, nothing resident); `single_instance` (ex0 alone) is the metric's "DO-phase ms, 50-agent
-          instance".
+          of csdo.cc:111-148 (`do_phase_e2e`: ONE csdo_do_phase call - bridge on the library's host threads, pack + H2D,
+          kernels writing their results into page-locked host memory, scatter; streamed in chunks of worlds where the job is
+          of one kernel class - host wall clock, nothing resident); `single_instance` (ex0 alone) is the metric's "DO-phase
+          ms, 50-agent instance".
 roofline: `fp64` and `lds` price the ADMM iterations against the two resources the kernel actually uses (DESIGN section 5 writes
           the counts out: F_iter = 718 Nt + 88 K + 2592 flop and L_iter = 8 (139 Nt + 42 K + 1440) LDS bytes per agent-iteration,
           against 78.6 TFLOP/s fp64 vector and 157 TB/s LDS); the contract's figure is the nominal HBM roofline of SURVEY 8(d): algorithmic bytes W_iter = 2280*Nt + 416*K_a per agent-iteration summed
@@ -46,7 +47,8 @@ roofline: `fp64` and `lds` price the ADMM iterations against the two resources t
           launch stream inside csdo_dsqp_run) against 8 TB/s.  The working set is on-chip, so the kernel is latency
           bound, not HBM bound: `traffic` (HBM bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes),
           `hbm_counter_frac` and `valu_fp64_issue_frac` come from the newest profiles/rNN_pmc_summary.json and are null
-          when that profile was taken on a different workload or its step time is more than 20 % off this run's.
+          when that profile was taken on a different workload, from other kernel sources (its `kernel_source_hash` against the
+          running library's csdo_source_hash()) or its step time is more than 20 % off this run's.
 cpu_baseline: the oracle (CPU restatement of the reference + OSQP 0.6.3, kind "port") on the same batch with ONE thread
           pool over all its agents on all host cores (rank 0, N = 1 only).
 """

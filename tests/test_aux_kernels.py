@@ -44,6 +44,28 @@ def test_device_bridge_equals_host_bridge_and_the_oracle(gpu_handle, oracle, whi
     np.testing.assert_allclose(wd.planes["c"], wo.planes["c"], atol=1e-12, rtol=1e-14)
 
 
+@pytest.mark.parametrize("seed", [1, 4, 5, 7, 8, 11])
+def test_device_bridge_equals_host_bridge_on_random_worlds(gpu_handle, veh_parm, seed):
+    """The random worlds of tests/test_bridge.py (a few pairs to 14655, single-state paths, overlapping rectangles, horizons off every
+    block size): the device bridge, the host bridge on the library's threads and their batched forms return the same bytes."""
+    from tests.test_bridge import _random_paths
+    from csdotrajectoryplanning_amd.solver import interpolate_and_planes, interpolate_and_planes_batch_host
+    veh, parm = veh_parm
+    rng = np.random.default_rng(100 + seed)
+    Na = [1, 2, 3, 7, 16, 25, 40, 64, 5, 33, 12, 50][seed]
+    max_moves = [3, 1, 12, 30, 5, 21, 40, 11, 60, 17, 6, 26][seed]
+    crowd = [0.1, 0.02, 0.05, 0.4, 0.1, 0.15, 0.3, 0.2, 0.05, 0.1, 0.01, 0.25][seed]
+    st, ac, po, G = _random_paths(rng, Na, 100.0, max_moves, crowd)
+    obs = np.zeros((0, 3))
+    host = interpolate_and_planes(st, ac, po, G, veh, parm, 100.0, 100.0, obs)
+    dev = gpu_handle.interpolate_and_planes(st, ac, po, G, veh, parm, 100.0, 100.0, obs)
+    _same_bridge(host, dev)
+    item = (st, ac, po, G, 100.0, 100.0, obs)
+    for batched in (interpolate_and_planes_batch_host([item, item], veh, parm), gpu_handle.interpolate_and_planes_batch([item, item], veh, parm)):
+        for b in batched:
+            _same_bridge(host, b)
+
+
 def test_device_bridge_1024_agents_in_one_world(gpu_handle):
     """The case K0 exists for: 1024 vehicles in ONE world, about 10^8 (t, i, j) candidates.  The coarse paths of
     21 instances are laid over each other (not a solvable planning instance: a stress input with very many neighbours)."""

@@ -1,0 +1,56 @@
+"""Every horizon from 4 to 343 timesteps: two vehicles of a room-map world (238 obstacles, their inter-vehicle planes) cut to Nt
+timesteps, two QPs each (a corridor refresh and a re-linearisation included).  The kernel classes, the reduction's depth, the tail's
+size and the waves' hand-overs all change along this axis (csrc/dsqp_class.h: 256 threads to 96 timesteps, 512 to 256 with a six- or an
+eight-node tail, 768 beyond; a wave boundary every 64 timesteps): the CPU test holds the lane-serial build of the device program to the
+oracle on every one of them, the GPU test holds the HIP kernels to the lane-serial build's bits - all 340 worlds in ONE batch."""
+import numpy as np
+import pytest
+
+HORIZONS = list(range(4, 344))
+THREADS = 8
+
+
+def _worlds():
+    from csdotrajectoryplanning_amd import workloads
+    from csdotrajectoryplanning_amd.problem import World
+    w, _ = workloads.build_job(workloads.workload_jobs("room50", 3)[2])
+    assert w.Nt == 343
+    s = w.subset(10, 12)
+    out = []
+    for nt in HORIZONS:
+        keep, off = [], [0]
+        for a in range(s.Na):
+            p = s.planes[s.plane_off[a]:s.plane_off[a + 1]]
+            p = p[p["t"] < nt]
+            keep.append(p)
+            off.append(off[-1] + len(p))
+        out.append(World(np.ascontiguousarray(s.x0_bar[:, :nt]), np.asarray(off, np.int32), np.concatenate(keep), s.dimx, s.dimy,
+                         s.obstacles, s.veh, s.parm).with_parm(max_iter=2))
+    return out
+
+
+def test_every_horizon_against_the_oracle(emu, oracle):
+    worlds = _worlds()
+    got, ref = emu.solve_batch(worlds, 0, THREADS), oracle.solve_batch(worlds, THREADS)
+    worst = 0.0
+    for w, g, r in zip(worlds, got, ref):
+        assert np.array_equal(g.sqp_iters, r.sqp_iters) and np.array_equal(g.admm_iters, r.admm_iters), (w.Nt, g.admm_iters, r.admm_iters)
+        assert np.array_equal(g.last_status, r.last_status) and g.solver_status == r.solver_status, w.Nt
+        d = float(np.abs(g.solutions - r.solutions).max())
+        assert d <= 1e-6 and np.abs(g.corridors - r.corridors).max() <= 1e-6, (w.Nt, d)
+        worst = max(worst, d)
+    print("340 horizons, two QPs: max |difference| to the oracle %.1e" % worst)
+
+
+@pytest.mark.gpu
+def test_every_horizon_hip_equals_lane_serial_bits(gpu_handle, emu):
+    from csdotrajectoryplanning_amd import abi
+    worlds = _worlds()
+    got = gpu_handle.solve_batch(worlds)
+    classes = sorted({(g["threads"], g["residency_mode"]) for g in gpu_handle.launch_groups()})
+    assert {c[0] for c in classes} >= {256, 512, 768}, classes          # the axis crosses the kernel classes
+    ser = emu.solve_batch(worlds, 0, 16)
+    for w, g, s in zip(worlds, got, ser):
+        assert np.array_equal(g.solutions, s.solutions) and np.array_equal(g.corridors, s.corridors), w.Nt
+        assert np.array_equal(g.admm_iters, s.admm_iters) and np.array_equal(g.sqp_iters, s.sqp_iters) and np.array_equal(g.last_status, s.last_status), w.Nt
+    assert abi.CSDO_MAX_NT >= HORIZONS[-1]

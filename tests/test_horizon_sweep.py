@@ -54,3 +54,30 @@ def test_every_horizon_hip_equals_lane_serial_bits(gpu_handle, emu):
         assert np.array_equal(g.solutions, s.solutions) and np.array_equal(g.corridors, s.corridors), w.Nt
         assert np.array_equal(g.admm_iters, s.admm_iters) and np.array_equal(g.sqp_iters, s.sqp_iters) and np.array_equal(g.last_status, s.last_status), w.Nt
     assert abi.CSDO_MAX_NT >= HORIZONS[-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("refinement", [1, 2])
+def test_every_third_horizon_of_the_refined_kernels(gpu_handle, emu, refinement):
+    """The REFINE instantiations (csdo_qp_parm::solve_refinement = 1: a second solve on the KKT residual; = 2: the residual joins the next
+    right-hand side) along the same axis, every third horizon: HIP = the lane-serial build's bits."""
+    worlds = [w.with_parm(solve_refinement=refinement) for w in _worlds()[::3]]
+    got = gpu_handle.solve_batch(worlds)
+    ser = emu.solve_batch(worlds, 0, 16)
+    for w, g, s in zip(worlds, got, ser):
+        assert np.array_equal(g.solutions, s.solutions) and np.array_equal(g.admm_iters, s.admm_iters) and np.array_equal(g.last_status, s.last_status), (refinement, w.Nt)
+
+
+@pytest.mark.parametrize("refinement", [1, 2])
+def test_every_fifth_horizon_refined_against_the_oracle(emu, oracle, refinement):
+    """... and against the oracle on the CPU: the refined solves change the iterates by less than the unrefined solve's error (identical
+    counts on all but a few worlds - a termination check 25 iterations earlier or later is allowed where it happens -, 1e-5)."""
+    worlds = [w.with_parm(solve_refinement=refinement) for w in _worlds()[::5]]
+    got, ref = emu.solve_batch(worlds, 0, THREADS), oracle.solve_batch(worlds, THREADS)
+    off = 0
+    for w, g, r in zip(worlds, got, ref):
+        if not (np.array_equal(g.admm_iters, r.admm_iters) and np.array_equal(g.sqp_iters, r.sqp_iters)):
+            off += 1
+            continue
+        assert float(np.abs(g.solutions - r.solutions).max()) <= 1e-5, (refinement, w.Nt)
+    assert off <= 2, off

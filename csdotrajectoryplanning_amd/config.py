@@ -49,7 +49,9 @@ def qp_parm_from_config(cfg=None, adaptive_rho_interval=25, solve_refinement=0) 
     p.dt = step / p.max_v / (p.num_interpolation + 1) / float(cfg["decelerate_factor"])
     p.fixed_corridor = int(bool(cfg["fixed_corridor"]))
     p.adaptive_rho_interval = int(adaptive_rho_interval)
-    p.solve_refinement = int(bool(solve_refinement))   # csdo_qp_parm::solve_refinement (include/csdo_dsqp.h): the accurate solve, ~2 x the time
+    # csdo_qp_parm::solve_refinement (include/csdo_dsqp.h): 1 = a second solve on the KKT residual per iteration (~1.8 x the time),
+    # 2 = the lagged form (~1.3 x); True counts as 1
+    p.solve_refinement = int(solve_refinement) if int(solve_refinement) in (1, 2) else 0
     return p
 
 

@@ -657,7 +657,9 @@ def main():
         from csdotrajectoryplanning_amd import _lib as _csdo_lib
         lib_hash = _csdo_lib.lib().csdo_source_hash().decode()
         if world_size == 1:
-            traffic, hbm_frac, valu_frac, pmc_src = _newest_pmc(args.workload, elapsed_max / steps * 1e3, lib_hash)
+            # (the refined kernels are other kernels: their counters come from a profile of their own, `<workload>_refine<m>`)
+            pmc_label = args.workload + ("_refine%d" % int(args.solve_refinement) if args.solve_refinement else "")
+            traffic, hbm_frac, valu_frac, pmc_src = _newest_pmc(pmc_label, elapsed_max / steps * 1e3, lib_hash)
         # what the ADMM iterations cost in the two resources the kernel does use (counts per agent-iteration)
         K_agent = np.concatenate([(w.plane_off[1:] - w.plane_off[:-1]).astype("float64") for w in worlds])
         Nt_agent = np.concatenate([np.full(w.Na, float(w.Nt)) for w in worlds])

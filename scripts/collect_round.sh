@@ -4,6 +4,9 @@
 set -u
 cd "$(dirname "$0")/.."
 TAG=${1:-r04}
+for w in map100_refine1 map100_refine2; do
+  [ -d gpurun_out/${TAG}_$w ] && python scripts/summarize_profiles.py gpurun_out $TAG $w > /dev/null 2>&1
+done
 for w in map100 map50 synth1024 room50 agents100; do
   python scripts/summarize_profiles.py gpurun_out $TAG $w > /dev/null 2>&1
   [ -f gpurun_out/$TAG/bench_$w.json ] && tail -1 gpurun_out/$TAG/bench_$w.json > profiles/${TAG}_bench_$w.json

@@ -55,11 +55,11 @@ PY
       w=${arg%%:*}; lib=${arg#*:}; [ "$lib" == "$arg" ] && lib=""
       tagl=$(basename ${lib:-prof} .so)
       CSDO_DIAG_LIB=${lib:-csdotrajectoryplanning_amd/libcsdo_hip_prof.so} timeout 900 python scripts/profile_phases_sum.py 0,1,2,4,5,6,7,9 $w > $O/phases_${w}_$tagl.txt 2>&1; head -12 $O/phases_${w}_$tagl.txt ;;
-    profile)
-      bash scripts/profile_round.sh $TAG $arg ;;
+    profile)   # profile:<workload>[:<solve_refinement>]
+      bash scripts/profile_round.sh $TAG ${arg%%:*} $([ "${arg#*:}" != "$arg" ] && echo ${arg#*:}) ;;
     summarize)  # the counter summaries of this call's profile:<workload> steps into profiles/ ON THE BOX, so that bench lines run later in
                 # the same call (round) quote counters taken from the very library they time (bench.py: _newest_pmc compares the hashes)
-      for w in map100 map50 synth1024 room50 agents100; do
+      for w in map100 map50 synth1024 room50 agents100 map100_refine1 map100_refine2; do
         [ -d gpurun_out/${TAG}_$w ] && python scripts/summarize_profiles.py gpurun_out $TAG $w > /dev/null 2>&1
       done
       grep -h kernel_source_hash profiles/${TAG}_*pmc_summary.json | sort | uniq -c ;;

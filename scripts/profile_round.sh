@@ -1,13 +1,15 @@
 #!/bin/bash
 # Profiling call of a round (run through gpurun from the repo root): kernel trace + separate PMC passes.
-#   usage: profile_round.sh <tag> [workload]
+#   usage: profile_round.sh <tag> [workload] [solve_refinement]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r02}
 WL=${2:-map100}
 cd /tmp && export TMPDIR=/tmp
+REFINE=${3:-0}     # csdo_qp_parm::solve_refinement of the profiled run (the REFINE kernels): summaries are labelled <workload>_refine<m>
 ARGS="--workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --setup-procs 1 --skip-single-instance"
 O=$R/gpurun_out/${TAG}_${WL}
+if [ "$REFINE" != "0" ]; then ARGS="$ARGS --solve-refinement $REFINE"; O=${O}_refine$REFINE; fi
 mkdir -p $O
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py $ARGS > $O/trace.log 2>&1
 timeout -s KILL 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/fetch -o fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1

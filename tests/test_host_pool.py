@@ -123,3 +123,18 @@ def test_pool_under_thread_sanitizer(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe], env=dict(os.environ, CSDO_HOST_THREADS="8"), capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr and run.stdout.strip().endswith("ok"), (run.stdout, run.stderr[-3000:])
+
+
+def test_bridge_and_packing_under_address_and_ub_sanitizers(tmp_path):
+    """tests/cpp/sanitize_host.cc + csrc/bridge_host.cc built with -fsanitize=address,undefined: no report on thirty random worlds."""
+    exe = str(tmp_path / "sanitize_host")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                         os.path.join(ROOT, "tests", "cpp", "sanitize_host.cc"),
+                         os.path.join(ROOT, "csdotrajectoryplanning_amd", "csrc", "bridge_host.cc"), "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "asan" in (cc.stderr or "").lower():
+        import pytest
+        pytest.skip("no sanitizer runtime here")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe], env=dict(os.environ, CSDO_HOST_THREADS="8"), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok") and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, \
+        (run.stdout[-500:], run.stderr[-3000:])
